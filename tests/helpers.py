@@ -1,0 +1,85 @@
+"""Shared test helpers: deterministic weights and synthetic BioLiP-shaped inputs.
+
+Nothing here reads /root/reference: the GPU box does not have it.
+"""
+import math
+import os
+
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+TINY = dict(hidden_size=256, num_heads=4, intermediate_size=512, num_hidden_layers=2,
+            max_seq_len=16)
+FULL_STRUCT = dict(hidden_size=768, num_heads=12, intermediate_size=1024, num_hidden_layers=12)
+FULL_SEQ = dict(hidden_size=768, num_heads=12, intermediate_size=1024, num_hidden_layers=6)
+
+
+def seeded_state_dict(shapes, seed=0, zero_relkey=False):
+    """Deterministic weights from (key -> shape), independent of any module's own init.
+
+    Linear weights ~ N(0, 1/fan_in), biases ~ 0.1 N(0,1), LayerNorm gamma = 1 + 0.1 N(0,1),
+    Fourier buffer W ~ 2*pi*N(0,1) (structure_model/model.py:82), distance_embedding ~ N(0,1)
+    (nn.Embedding default) or zeros when ``zero_relkey``.
+    The same function feeds the reference (fixture generation) and product + oracle (tests).
+    """
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for key in sorted(shapes):
+        shape = tuple(shapes[key])
+        r = torch.randn(shape, generator=g, dtype=torch.float32)
+        if key.endswith("distance_embedding.weight"):
+            v = torch.zeros(shape) if zero_relkey else r
+        elif key.endswith("timestep_projector.W"):
+            v = r * 2 * math.pi
+        elif "LayerNorm.weight" in key or "layer_norm.weight" in key:
+            v = 1.0 + 0.1 * r
+        elif key.endswith(".bias"):
+            v = 0.1 * r
+        elif len(shape) == 2:
+            v = r / math.sqrt(shape[1])
+        else:
+            v = r
+        sd[key] = v.contiguous()
+    return sd
+
+
+def synthetic_pockets(batch, max_len, seed=0, lig_range=(5, 30), rec_range=(20, None),
+                      with_ligand_seq=False):
+    """Synthetic BioLiP-shaped padded batch in the dataset.py tensor layout
+    (structure_model/dataset.py:119-132): dihedrals ~ U(-pi,pi), bond angles ~ N(1.95,0.1),
+    uniform one-hot residues, zero padding, float masks."""
+    g = torch.Generator().manual_seed(seed)
+    rec_hi = rec_range[1] or max_len
+    lig_hi = min(lig_range[1], max_len)
+    lig_len = torch.randint(min(lig_range[0], lig_hi), lig_hi + 1, (batch,), generator=g)
+    rec_len = torch.randint(min(rec_range[0], rec_hi), rec_hi + 1, (batch,), generator=g)
+
+    def angles(lengths):
+        a = torch.empty(batch, max_len, 8)
+        a[..., :4] = (torch.rand(batch, max_len, 4, generator=g) * 2 - 1) * math.pi
+        a[..., 4:] = 1.95 + 0.1 * torch.randn(batch, max_len, 4, generator=g)
+        m = (torch.arange(max_len)[None, :] < lengths[:, None]).float()
+        return a * m[..., None], m
+
+    def onehot(mask):
+        idx = torch.randint(0, 20, (batch, max_len), generator=g)
+        return torch.nn.functional.one_hot(idx, 20).float() * mask[..., None]
+
+    lig_angles, lig_mask = angles(lig_len)
+    rec_angles, rec_mask = angles(rec_len)
+    out = {
+        "ligand_angles": lig_angles, "ligand_attn_mask": lig_mask,
+        "receptor_angles": rec_angles, "receptor_attn_mask": rec_mask,
+        "receptor_seq": onehot(rec_mask),
+        "ligand_length": lig_len, "receptor_length": rec_len,
+    }
+    if with_ligand_seq:
+        out["ligand_seq"] = onehot(lig_mask)
+    return out
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|max, tiny): the "relative fp32" figure the tests assert on."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
