@@ -1,0 +1,190 @@
+"""BERT encoder/decoder stacks with ``relative_key`` self-attention, executed by HIP kernels.
+
+Mirrors the module tree -- and therefore the ``state_dict`` key names, the checkpoint wire
+format -- of transformers==4.38.2 ``BertEncoder`` / ``BertLayer`` /
+``BertAttention`` as the reference instantiates them (structure_model/model.py:16-20,40,171,177),
+but none of that package's code runs: the nn.Modules below only own parameters, and ``run_*``
+execute the math as fused gfx950 kernels on [B*L, H] row-major activations.
+"""
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+@dataclass
+class BertConfig:
+    """The subset of transformers.BertConfig the reference sets (structure_model/sample.py:160-183).
+    Any object with these attributes (e.g. a real transformers.BertConfig) is accepted too."""
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    intermediate_size: int = 1024
+    num_hidden_layers: int = 12
+    max_position_embeddings: int = 64
+    position_embedding_type: str = "relative_key"
+    hidden_dropout_prob: float = 0.1
+    attention_probs_dropout_prob: float = 0.1
+    layer_norm_eps: float = 1e-12
+    hidden_act: str = "gelu"
+    use_cache: bool = False
+    is_decoder: bool = False
+    add_cross_attention: bool = False
+
+
+def _check_config(cfg):
+    head = cfg.hidden_size // cfg.num_attention_heads
+    if cfg.hidden_size % cfg.num_attention_heads or head != 64:
+        raise ValueError(f"HIP attention kernel needs head dim 64 (hidden {cfg.hidden_size}, "
+                         f"heads {cfg.num_attention_heads})")
+    if cfg.hidden_size not in (256, 512, 768, 1024):
+        raise ValueError("HIP row kernels need hidden_size in {256,512,768,1024}")
+    if cfg.intermediate_size % 128:
+        raise ValueError("HIP GEMM needs intermediate_size % 128 == 0")
+    if getattr(cfg, "hidden_act", "gelu") != "gelu":
+        raise ValueError("only the exact-erf GELU the reference uses is implemented")
+    if cfg.position_embedding_type not in ("relative_key", "absolute"):
+        raise ValueError(f"unsupported position_embedding_type {cfg.position_embedding_type}")
+
+
+# ----------------------------------------------------------------------------- parameter tree
+class BertSelfAttention(nn.Module):
+    def __init__(self, cfg, position_embedding_type=None):
+        super().__init__()
+        h = cfg.hidden_size
+        self.query, self.key, self.value = nn.Linear(h, h), nn.Linear(h, h), nn.Linear(h, h)
+        self.position_embedding_type = position_embedding_type or cfg.position_embedding_type
+        self.max_position_embeddings = cfg.max_position_embeddings
+        if self.position_embedding_type == "relative_key":
+            self.distance_embedding = nn.Embedding(2 * cfg.max_position_embeddings - 1,
+                                                   h // cfg.num_attention_heads)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, cfg, position_embedding_type=None):
+        super().__init__()
+        _check_config(cfg)
+        self.self = BertSelfAttention(cfg, position_embedding_type)
+        self.output = BertSelfOutput(cfg)
+        self.num_heads = cfg.num_attention_heads
+        self.eps = cfg.layer_norm_eps
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = BertAttention(cfg)
+        if cfg.add_cross_attention:
+            if not cfg.is_decoder:
+                raise ValueError("cross attention needs is_decoder=True")
+            # 4.38.2 BertLayer builds the cross attention with position_embedding_type="absolute"
+            self.crossattention = BertAttention(cfg, position_embedding_type="absolute")
+        self.intermediate = BertIntermediate(cfg)
+        self.output = BertOutput(cfg)
+        self.eps = cfg.layer_norm_eps
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        _check_config(cfg)
+        self.config = cfg
+        self.layer = nn.ModuleList([BertLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+
+# ----------------------------------------------------------------------------- packed weights
+def _packed(owner, name, tensors):
+    """cat() of per-projection weights, cached on the owner and rebuilt when any source
+    parameter changes (in-place update or re-assignment)."""
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    cache = owner.__dict__.setdefault("_e3d_pack", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, torch.cat([t.detach() for t in tensors], dim=0).contiguous())
+        cache[name] = hit
+    return hit[1]
+
+
+def qkv_weights(sa):
+    return (_packed(sa, "w_qkv", [sa.query.weight, sa.key.weight, sa.value.weight]),
+            _packed(sa, "b_qkv", [sa.query.bias, sa.key.bias, sa.value.bias]))
+
+
+def kv_weights(sa):
+    return (_packed(sa, "w_kv", [sa.key.weight, sa.value.weight]),
+            _packed(sa, "b_kv", [sa.key.bias, sa.value.bias]))
+
+
+# ----------------------------------------------------------------------------- executors
+def run_self_attention(att, x, mask, B, L):
+    """BertAttention on x [B*L,H] with key padding mask [B,L] (1/0): fused QKV GEMM ->
+    fused relative-key attention -> out-proj GEMM -> residual + LayerNorm."""
+    sa = att.self
+    H = x.shape[1]
+    w, b = qkv_weights(sa)
+    qkv = ops.gemm(x, w, b)
+    relkey = sa.position_embedding_type == "relative_key"
+    ctx = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, att.num_heads, L, L, key_mask=mask,
+                        dist_emb=sa.distance_embedding.weight if relkey else None,
+                        max_pos=sa.max_position_embeddings)
+    o = ops.gemm(ctx, att.output.dense.weight, att.output.dense.bias)
+    return ops.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+
+
+def project_cross_kv(att, enc):
+    """K/V projection of the encoder states for one decoder layer -> [B*Lk, 2H].  It depends on
+    neither the timestep nor the noised ligand, so samplers compute it once."""
+    w, b = kv_weights(att.self)
+    return ops.gemm(enc, w, b)
+
+
+def run_cross_attention(att, x, kv, enc_mask, B, Lq, Lk):
+    H = x.shape[1]
+    q = ops.gemm(x, att.self.query.weight, att.self.query.bias)
+    ctx = ops.attention(q, kv[:, :H], kv[:, H:], B, att.num_heads, Lq, Lk, key_mask=enc_mask)
+    o = ops.gemm(ctx, att.output.dense.weight, att.output.dense.bias)
+    return ops.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+
+
+def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None):
+    x = run_self_attention(layer.attention, x, mask, B, L)
+    if hasattr(layer, "crossattention"):
+        if cross_kv is None:
+            raise ValueError("decoder layer needs encoder states")
+        x = run_cross_attention(layer.crossattention, x, cross_kv, enc_mask, B, L, Lk)
+    inter = ops.gemm(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
+    o = ops.gemm(inter, layer.output.dense.weight, layer.output.dense.bias)
+    return ops.residual_layernorm(o, x, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps)
+
+
+def run_encoder(encoder, x, mask, B, L, enc=None, enc_mask=None, Lk=None, cross_kv=None):
+    """BertEncoder(...).last_hidden_state on flat activations.  ``cross_kv`` (list, one per
+    layer) short-cuts the per-layer K/V projection of ``enc``."""
+    for i, layer in enumerate(encoder.layer):
+        kv = None
+        if hasattr(layer, "crossattention"):
+            kv = cross_kv[i] if cross_kv is not None else project_cross_kv(layer.crossattention, enc)
+        x = run_layer(layer, x, mask, B, L, kv, enc_mask, Lk)
+    return x

@@ -1,0 +1,104 @@
+"""Blocks shared by the structure and sequence denoisers (the reference duplicates them:
+structure_model/model.py:27-154 == sequence_model/model.py:26-153).  Parameter containers keep
+the reference attribute names (checkpoint keys); ``run`` methods execute on HIP kernels."""
+import math
+
+import torch
+from torch import nn
+
+from . import bert, ops
+
+
+class SELayer(nn.Module):
+    """adaLN-gated attention + MLP block (structure_model/model.py:27-67)."""
+
+    def __init__(self, bert_config, mlp_ratio=4.0):
+        super().__init__()
+        h = bert_config.hidden_size
+        self.norm1 = nn.LayerNorm(h, elementwise_affine=False)
+        self.norm2 = nn.LayerNorm(h, elementwise_affine=False)
+        self.adaLN_modulation = nn.Sequential(nn.Linear(h, h, bias=True), nn.SiLU(),
+                                              nn.Linear(h, 6 * h, bias=True))
+        self.attn = bert.BertAttention(bert_config)
+        self.mlp = nn.Sequential(nn.Linear(h, int(h * mlp_ratio)), nn.GELU(),
+                                 nn.Dropout(bert_config.hidden_dropout_prob),
+                                 nn.Linear(int(h * mlp_ratio), h),
+                                 nn.Dropout(bert_config.hidden_dropout_prob))
+        nn.init.zeros_(self.adaLN_modulation[0].weight)
+        nn.init.zeros_(self.adaLN_modulation[0].bias)
+
+    def run(self, x, c, mask, B, L):
+        """x [B*L,H]; c [B*L,H] (per token) or [B,H] (one conditioning row per item)."""
+        rows_per_cond = x.shape[0] // c.shape[0]
+        assert rows_per_cond in (1, L), (x.shape, c.shape)
+        m0, m2 = self.adaLN_modulation[0], self.adaLN_modulation[2]
+        mod = ops.gemm(ops.gemm(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
+        att = bert.run_self_attention(self.attn, x, mask, B, L)
+        x = ops.adaln_gate(x, att, mod, 0, rows_per_cond)
+        h = ops.gemm(x, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_GELU)
+        h = ops.gemm(h, self.mlp[3].weight, self.mlp[3].bias)
+        return ops.adaln_gate(x, h, mod, 1, rows_per_cond)
+
+
+class GaussianFourierProjection(nn.Module):
+    """structure_model/model.py:69-98.  Kept as three tiny torch device ops on purpose: with raw
+    integer timesteps the sin/cos arguments reach ~1e5 rad, and the reference's op order
+    (t*W, *2, *pi in fp32) fixes which fp32 argument is reduced."""
+
+    def __init__(self, embed_dim=384, scale=2 * math.pi):
+        super().__init__()
+        self.register_buffer("W", torch.randn(embed_dim // 2) * scale)
+
+    def forward(self, x):
+        if x.ndim > 1:
+            x = x.squeeze()
+        elif x.ndim < 1:
+            x = x.unsqueeze(0)
+        if x.ndim < 1:
+            x = x.unsqueeze(0)
+        x_proj = x[:, None] * self.W[None, :] * 2 * torch.pi
+        return torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+
+
+class BertEmbeddings(nn.Module):
+    """Linear -> LayerNorm -> dropout(eval: identity) (structure_model/model.py:100-118)."""
+
+    def __init__(self, in_features, bert_config):
+        super().__init__()
+        self.linear = nn.Linear(in_features, bert_config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(bert_config.hidden_size, eps=bert_config.layer_norm_eps)
+        self.dropout = nn.Dropout(bert_config.hidden_dropout_prob)
+
+    def run(self, x2d, post_add=None, rows_per_add=1):
+        return ops.embed_layernorm(x2d, self.linear.weight, self.linear.bias, self.LayerNorm.weight,
+                                   self.LayerNorm.bias, self.LayerNorm.eps, post_add, rows_per_add)
+
+
+class Predictor(nn.Module):
+    """AnglesPredictor / AminoAcidPredictor: dense -> GELU -> LayerNorm -> dense
+    (structure_model/model.py:120-154)."""
+
+    def __init__(self, d_model, d_out, eps=1e-12):
+        super().__init__()
+        self.d_model, self.d_out = d_model, d_out
+        self.dense1 = nn.Linear(d_model, d_model)
+        self.layer_norm = nn.LayerNorm(d_model, eps=eps)
+        self.dense2 = nn.Linear(d_model, d_out)
+
+    def run(self, x):
+        h = ops.gemm(x, self.dense1.weight, self.dense1.bias, ops.ACT_GELU)
+        h = ops.residual_layernorm(h, None, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return ops.head_linear(h, self.dense2.weight, self.dense2.bias)
+
+
+def flat2d(x):
+    """[B,L,F] -> contiguous fp32 [B*L,F] view for the kernels."""
+    return x.reshape(-1, x.shape[-1]).contiguous().float()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("the denoiser runs on HIP kernels only: move the model and its inputs to a "
+                               "GPU device (there is no CPU fallback; the CPU oracle lives in oracle/ and is "
+                               "test infrastructure)")

@@ -1,0 +1,209 @@
+// HBM-bound row kernels: LayerNorm epilogues, adaLN gate, feature embeddings, output head.
+// One wavefront per row of H = 256*V floats; a lane keeps its V float4 (columns 4*(64*i+lane))
+// in registers, so every row is read once and written once with 16-byte coalesced accesses and
+// the mean/variance are two wave reductions (shuffles, no LDS).
+#include "e3d_common.h"
+
+namespace {
+
+template <int V>
+__device__ __forceinline__ void row_load(f32x4 (&r)[V], const float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + 4 * (64 * i + lane));
+}
+
+template <int V>
+__device__ __forceinline__ void row_store(const f32x4 (&r)[V], float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) *reinterpret_cast<f32x4*>(p + 4 * (64 * i + lane)) = r[i];
+}
+
+// in-place normalise: r <- (r - mean) * rstd ; two-pass (centered) variance, biased (1/H)
+template <int V>
+__device__ __forceinline__ void row_normalize(f32x4 (&r)[V], float eps) {
+    constexpr float inv_h = 1.0f / (256 * V);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += (r[i][0] + r[i][1]) + (r[i][2] + r[i][3]);
+    const float mean = wave_sum(s) * inv_h;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[i][j] -= mean;
+            ss += r[i][j] * r[i][j];
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_h + eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] *= rstd;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void residual_layernorm_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int M) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 r[V], t[V];
+    row_load<V>(r, x + (int64_t)row * H, lane);
+    if (res) {
+        row_load<V>(t, res + (int64_t)row * H, lane);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] += t[i];
+    }
+    row_normalize<V>(r, eps);
+    f32x4 g[V], b[V];
+    row_load<V>(g, gamma, lane);
+    row_load<V>(b, beta, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = r[i] * g[i] + b[i];
+    row_store<V>(r, out + (int64_t)row * H, lane);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void adaln_gate_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ y,
+                                                         const float* __restrict__ mod, int branch,
+                                                         int rows_per_cond, float* __restrict__ out,
+                                                         int M) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 r[V], xr[V], sh[V], sc[V], ga[V];
+    row_load<V>(r, y + (int64_t)row * H, lane);
+    row_normalize<V>(r, 1e-5f);
+    const float* mrow = mod + (int64_t)(row / rows_per_cond) * 6 * H + (int64_t)branch * 3 * H;
+    row_load<V>(sh, mrow, lane);
+    row_load<V>(sc, mrow + H, lane);
+    row_load<V>(ga, mrow + 2 * H, lane);
+    row_load<V>(xr, x + (int64_t)row * H, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = xr[i] + ga[i] * (r[i] * (1.0f + sc[i]) + sh[i]);
+    row_store<V>(r, out + (int64_t)row * H, lane);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void embed_layernorm_kernel(
+    const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ post_add, int rows_per_add, float* __restrict__ out, int M) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float xin[32];
+    const float* xr = x + (int64_t)row * F;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) xin[f] = f < F ? xr[f] : 0.f;
+    f32x4 r[V];
+    row_load<V>(r, bias, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* w = W + (int64_t)(4 * (64 * i + lane) + j) * F;
+            float acc = 0.f;
+#pragma unroll
+            for (int f = 0; f < 32; ++f)  // static register indices; F is wave-uniform
+                if (f < F) acc = fmaf(xin[f], w[f], acc);
+            r[i][j] += acc;
+        }
+    row_normalize<V>(r, eps);
+    f32x4 g[V], b[V];
+    row_load<V>(g, gamma, lane);
+    row_load<V>(b, beta, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = r[i] * g[i] + b[i];
+    if (post_add) {
+        f32x4 a[V];
+        row_load<V>(a, post_add + (int64_t)(row / rows_per_add) * H, lane);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] += a[i];
+    }
+    row_store<V>(r, out + (int64_t)row * H, lane);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ out, int M, int Nout) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 r[V];
+    row_load<V>(r, x + (int64_t)row * H, lane);
+    float mine = 0.f;
+    for (int n = 0; n < Nout; ++n) {
+        f32x4 w[V];
+        row_load<V>(w, W + (int64_t)n * H, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = fmaf(r[i][j], w[i][j], s);
+        s = wave_sum(s);
+        if (lane == n) mine = s + b[n];
+    }
+    if (lane < Nout) out[(int64_t)row * Nout + lane] = mine;
+}
+
+#define DISPATCH_V(H, CALL)                                             \
+    switch (H) {                                                        \
+        case 256: { constexpr int V = 1; CALL; } break;                 \
+        case 512: { constexpr int V = 2; CALL; } break;                 \
+        case 768: { constexpr int V = 3; CALL; } break;                 \
+        case 1024: { constexpr int V = 4; CALL; } break;                \
+        default: E3D_REQUIRE(false, "row op: H must be 256/512/768/1024 (H=%d)", H); \
+    }
+
+}  // namespace
+
+extern "C" int e3d_residual_layernorm_fwd(const float* x, const float* residual,
+                                          const float* gamma, const float* beta, float eps,
+                                          float* out, int M, int H, void* stream) {
+    E3D_REQUIRE(x && gamma && beta && out && M > 0, "residual_layernorm: bad arguments");
+    const dim3 grid((M + 3) / 4), block(256);
+    DISPATCH_V(H, hipLaunchKernelGGL(residual_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x,
+                                     residual, gamma, beta, eps, out, M));
+    return e3d_launch_status("e3d_residual_layernorm_fwd");
+}
+
+extern "C" int e3d_adaln_gate_fwd(const float* x, const float* y, const float* mod, int branch,
+                                  int rows_per_cond, float* out, int M, int H, void* stream) {
+    E3D_REQUIRE(x && y && mod && out && M > 0, "adaln_gate: bad arguments");
+    E3D_REQUIRE((branch == 0 || branch == 1) && rows_per_cond >= 1, "adaln_gate: branch=%d rows_per_cond=%d",
+                branch, rows_per_cond);
+    const dim3 grid((M + 3) / 4), block(256);
+    DISPATCH_V(H, hipLaunchKernelGGL(adaln_gate_kernel<V>, grid, block, 0, (hipStream_t)stream, x, y, mod, branch,
+                                     rows_per_cond, out, M));
+    return e3d_launch_status("e3d_adaln_gate_fwd");
+}
+
+extern "C" int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, const float* b,
+                                       const float* gamma, const float* beta, float eps,
+                                       const float* post_add, int rows_per_add, float* out, int M,
+                                       int H, void* stream) {
+    E3D_REQUIRE(x && W && b && gamma && beta && out && M > 0, "embed_layernorm: bad arguments");
+    E3D_REQUIRE(F >= 1 && F <= 32, "embed_layernorm: F must be in [1,32] (F=%d)", F);
+    E3D_REQUIRE(!post_add || rows_per_add >= 1, "embed_layernorm: rows_per_add=%d", rows_per_add);
+    const dim3 grid((M + 3) / 4), block(256);
+    DISPATCH_V(H, hipLaunchKernelGGL(embed_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x, F, W, b,
+                                     gamma, beta, eps, post_add, rows_per_add, out, M));
+    return e3d_launch_status("e3d_embed_layernorm_fwd");
+}
+
+extern "C" int e3d_head_linear_fwd(const float* x, const float* W, const float* b, float* out,
+                                   int M, int H, int Nout, void* stream) {
+    E3D_REQUIRE(x && W && b && out && M > 0, "head_linear: bad arguments");
+    E3D_REQUIRE(Nout >= 1 && Nout <= 32, "head_linear: Nout must be in [1,32] (Nout=%d)", Nout);
+    const dim3 grid((M + 3) / 4), block(256);
+    DISPATCH_V(H, hipLaunchKernelGGL(head_linear_kernel<V>, grid, block, 0, (hipStream_t)stream, x, W, b, out, M,
+                                     Nout));
+    return e3d_launch_status("e3d_head_linear_fwd");
+}

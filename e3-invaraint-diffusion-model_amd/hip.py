@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI HIP library (include/e3d_hip.h -> libe3d_hip.so).
+
+The library is the product's only compute path: there is no CPU or eager-PyTorch fallback.
+``lib()`` raises if the shared object is missing (build it with ``__graft_entry__.build()`` or
+``csrc/build.sh``).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe3d_hip.so")
+ABI_VERSION = 1
+
+_P = c_void_p
+_SIGNATURES = {
+    "e3d_abi_version": (c_int, []),
+    "e3d_last_error": (c_char_p, []),
+    "e3d_gemm_bias_act_f32": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "e3d_relkey_attn_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                    _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, c_int, _P]),
+    "e3d_adaln_gate_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "e3d_embed_layernorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int, c_int, _P]),
+    "e3d_head_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "e3d_ddpm_step_wrap": (c_int, [_P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P, c_int64, _P]),
+    "e3d_q_sample_wrap": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, _P]),
+    "e3d_discrete_posterior_sample": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "e3d_discrete_q_sample": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; fail loudly when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not found: the HIP extension is the only compute path of this package "
+                "(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the header and the .so disagree
+            fn.restype, fn.argtypes = res, args
+        got = handle.e3d_abi_version()
+        if got != ABI_VERSION:
+            raise HipExtensionMissing(f"{LIB_PATH}: ABI version {got}, binding expects {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().e3d_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,161 @@
+"""Tensor-level wrappers over the C-ABI: allocate outputs with torch (device memory + stream
+plumbing only) and enqueue the HIP kernels on torch's current stream."""
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (this package has no CPU path), got {t.device}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a, weight, bias=None, act=ACT_NONE, out=None):
+    """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view."""
+    _chk(a, "gemm.a"); _chk(weight, "gemm.weight"); _chk(bias, "gemm.bias")
+    assert a.dim() == 2 and a.stride(1) == 1 and weight.is_contiguous()
+    M, K = a.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K, (a.shape, weight.shape)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
+    hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
+                                              out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
+    return out
+
+
+def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False):
+    """q [B*Lq, >=nh*64] / k, v [B*Lk, ...] row-strided 2-D views (e.g. slices of a fused QKV
+    buffer).  Returns ctx [B*Lq, nh*64] (and lse [B,nh,Lq])."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("key_mask", key_mask), ("dist_emb", dist_emb)):
+        _chk(t, "attention." + n)
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    assert q.shape[0] == B * Lq and k.shape[0] == B * Lk and v.shape[0] == B * Lk
+    if key_mask is not None:
+        assert key_mask.is_contiguous() and key_mask.shape == (B, Lk)
+    if dist_emb is not None:
+        assert dist_emb.is_contiguous() and dist_emb.shape == (2 * max_pos - 1, 64), dist_emb.shape
+    out = torch.empty((B * Lq, nh * 64), device=q.device, dtype=torch.float32)
+    lse = torch.empty((B, nh, Lq), device=q.device, dtype=torch.float32) if want_lse else None
+    hip.check(hip.lib().e3d_relkey_attn_fwd(
+        _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
+        _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
+        B, nh, Lq, Lk, _stream()), "e3d_relkey_attn_fwd")
+    return (out, lse) if want_lse else out
+
+
+def residual_layernorm(x, residual, gamma, beta, eps):
+    for n, t in (("x", x), ("residual", residual), ("gamma", gamma), ("beta", beta)):
+        _chk(t, "residual_layernorm." + n)
+    assert x.is_contiguous() and (residual is None or residual.is_contiguous())
+    M, H = x.shape
+    out = torch.empty_like(x)
+    hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps,
+                                                   _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
+    return out
+
+
+def adaln_gate(x, y, mod, branch, rows_per_cond):
+    for n, t in (("x", x), ("y", y), ("mod", mod)):
+        _chk(t, "adaln_gate." + n)
+    assert x.is_contiguous() and y.is_contiguous() and mod.is_contiguous()
+    M, H = x.shape
+    assert mod.shape[1] == 6 * H and mod.shape[0] * rows_per_cond == M, (mod.shape, M, rows_per_cond)
+    out = torch.empty_like(x)
+    hip.check(hip.lib().e3d_adaln_gate_fwd(_p(x), _p(y), _p(mod), branch, rows_per_cond, _p(out),
+                                           M, H, _stream()), "e3d_adaln_gate_fwd")
+    return out
+
+
+def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_add=1):
+    for n, t in (("x", x), ("weight", weight), ("bias", bias), ("gamma", gamma), ("beta", beta),
+                 ("post_add", post_add)):
+        _chk(t, "embed_layernorm." + n)
+    assert x.is_contiguous() and weight.is_contiguous()
+    M, F = x.shape
+    H = weight.shape[0]
+    assert weight.shape[1] == F
+    if post_add is not None:
+        assert post_add.is_contiguous() and post_add.shape == (M // rows_per_add, H)
+    out = torch.empty((M, H), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_embed_layernorm_fwd(_p(x), F, _p(weight), _p(bias), _p(gamma), _p(beta), eps,
+                                                _p(post_add), rows_per_add, _p(out), M, H, _stream()),
+              "e3d_embed_layernorm_fwd")
+    return out
+
+
+def head_linear(x, weight, bias):
+    for n, t in (("x", x), ("weight", weight), ("bias", bias)):
+        _chk(t, "head_linear." + n)
+    assert x.is_contiguous() and weight.is_contiguous()
+    M, H = x.shape
+    n_out = weight.shape[0]
+    out = torch.empty((M, n_out), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_head_linear_fwd(_p(x), _p(weight), _p(bias), _p(out), M, H, n_out, _stream()),
+              "e3d_head_linear_fwd")
+    return out
+
+
+def ddpm_step_wrap(x, eps_hat, noise, sqrt_recip_alpha, beta, sqrt_one_minus_ab, sigma, wrap=True, out=None):
+    for n, t in (("x", x), ("eps_hat", eps_hat), ("noise", noise)):
+        _chk(t, "ddpm_step_wrap." + n)
+    assert x.is_contiguous() and eps_hat.is_contiguous() and (noise is None or noise.is_contiguous())
+    if out is None:
+        out = torch.empty_like(x)
+    hip.check(hip.lib().e3d_ddpm_step_wrap(_p(x), _p(eps_hat), _p(noise), sqrt_recip_alpha, beta,
+                                           sqrt_one_minus_ab, sigma, int(wrap), _p(out), x.numel(), _stream()),
+              "e3d_ddpm_step_wrap")
+    return out
+
+
+def q_sample_wrap(x0, noise, t, sqrt_ab, sqrt_1mab):
+    for n, tt in (("x0", x0), ("noise", noise), ("sqrt_ab", sqrt_ab), ("sqrt_1mab", sqrt_1mab)):
+        _chk(tt, "q_sample_wrap." + n)
+    _chk(t, "q_sample_wrap.t", torch.int64)
+    assert x0.is_contiguous() and noise.is_contiguous() and t.is_contiguous()
+    B = x0.shape[0]
+    out = torch.empty_like(x0)
+    hip.check(hip.lib().e3d_q_sample_wrap(_p(x0), _p(noise), _p(t), _p(sqrt_ab), _p(sqrt_1mab), _p(out),
+                                          B, x0.numel() // B, _stream()), "e3d_q_sample_wrap")
+    return out
+
+
+def discrete_posterior_sample(xt_idx, logits, qsb, qtb, u=None, want_prob=False):
+    """xt_idx int32 [B,L]; logits [B,L,C]; qsb/qtb [B,C,C]; u [B,L] uniforms or None (argmax)."""
+    _chk(xt_idx, "xt_idx", torch.int32); _chk(logits, "logits"); _chk(qsb, "qsb"); _chk(qtb, "qtb"); _chk(u, "u")
+    B, L, C = logits.shape
+    assert xt_idx.is_contiguous() and logits.is_contiguous() and qsb.is_contiguous() and qtb.is_contiguous()
+    assert qsb.shape == (B, C, C) and qtb.shape == (B, C, C) and xt_idx.shape == (B, L)
+    out = torch.empty((B, L), device=logits.device, dtype=torch.int32)
+    prob = torch.empty((B, L, C), device=logits.device, dtype=torch.float32) if want_prob else None
+    hip.check(hip.lib().e3d_discrete_posterior_sample(
+        _p(xt_idx), _p(logits), _p(qsb), _p(qtb), _p(u), 0 if u is None else 1, _p(out), _p(prob),
+        B, L, C, _stream()), "e3d_discrete_posterior_sample")
+    return (out, prob) if want_prob else out
+
+
+def discrete_q_sample(x0_idx, qtb, u=None):
+    """x0_idx int32 [B,L] (-1 = padding row); qtb [B,C,C]; u [B,L] uniforms or None (argmax)."""
+    _chk(x0_idx, "x0_idx", torch.int32); _chk(qtb, "qtb"); _chk(u, "u")
+    B, L = x0_idx.shape
+    C = qtb.shape[-1]
+    assert x0_idx.is_contiguous() and qtb.is_contiguous() and qtb.shape == (B, C, C)
+    out = torch.empty((B, L), device=qtb.device, dtype=torch.int32)
+    hip.check(hip.lib().e3d_discrete_q_sample(_p(x0_idx), _p(qtb), _p(u), 0 if u is None else 1, _p(out),
+                                              B, L, C, _stream()), "e3d_discrete_q_sample")
+    return out

@@ -1,0 +1,123 @@
+/*
+ * e3d_hip.h -- C-ABI of the MI355X (gfx950) denoising hot path.
+ *
+ * The reference (LabJunBMI/E3-invaraint-diffusion-model) is pure Python and exposes no
+ * FFI/plugin interface of its own; its seam is the Python call
+ * surface of structure_model/{model,sample}.py and sequence_model/{model,sample}.py.  This
+ * header is therefore the boundary the reference-side binding (ctypes)
+ * would load: plain pointers and sizes, no torch types.  Each entry point cites the
+ * reference lines (relative to /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory (HBM), fp32 row-major unless stated, 16-byte aligned;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises with the host and nothing is allocated;
+ *   - return value: 0 = enqueued, <0 = argument error (message via e3d_last_error()),
+ *     >0 = hipError_t from the launch.
+ */
+#ifndef E3D_HIP_H
+#define E3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E3D_ABI_VERSION 1
+
+#define E3D_ACT_NONE 0
+#define E3D_ACT_GELU 1 /* exact erf GELU: transformers get_activation("gelu"), nn.GELU() */
+#define E3D_ACT_SILU 2 /* nn.SiLU in SELayer.adaLN_modulation, structure_model/model.py:34 */
+
+int e3d_abi_version(void);
+const char* e3d_last_error(void);
+
+/* out[M,N] = act(A[M,K] @ W[N,K]^T + bias[N]) -- every nn.Linear of the path
+ * (BertSelfAttention query/key/value, BertSelfOutput.dense, BertIntermediate, BertOutput:
+ * transformers 4.38.2 modeling_bert.py; SELayer.adaLN_modulation / mlp:
+ * structure_model/model.py:32-47; predictor dense1: structure_model/model.py:149-151).
+ * lda/ldc are row strides in elements.  Requires N % 128 == 0, K % 32 == 0.  bias may be NULL. */
+int e3d_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const float* bias,
+                          float* out, int64_t ldc, int M, int N, int K, int act, void* stream);
+
+/* Fused attention, head dim 64 ("edge aggregation" of the north star):
+ *   S = (Q K^T + R) / sqrt(64) + (1 - key_mask) * -10000;  out = softmax(S) V
+ *   R[l,r] = q_l . dist_emb[l - r + P - 1]   (relative_key, only when dist_emb != NULL)
+ * Replaces transformers 4.38.2 BertSelfAttention.forward as called from
+ * structure_model/model.py:40,62,197-213 and sequence_model/model.py:39,226-235, plus
+ * _exetend_attention_mask (structure_model/model.py:226-231).
+ *   q: token (b,l) head h at q + b*q_bs + l*q_rs + h*64 (element strides), same for k, v;
+ *   key_mask [B,Lk] holds 1.0/0.0 (NULL = all ones); out [B,Lq,nh*64];
+ *   lse (optional, [B,nh,Lq]) receives log-sum-exp of S rows for the backward pass.
+ * Requires Lq,Lk >= 1; with dist_emb: Lq == Lk <= P and dist_emb is [2P-1,64]. */
+int e3d_relkey_attn_fwd(const float* q, int64_t q_bs, int64_t q_rs,
+                        const float* k, int64_t k_bs, int64_t k_rs,
+                        const float* v, int64_t v_bs, int64_t v_rs,
+                        const float* dist_emb, int P, const float* key_mask,
+                        float* out, float* lse, int B, int nh, int Lq, int Lk, void* stream);
+
+/* out[M,H] = LayerNorm_eps(x[M,H] (+ residual[M,H])) * gamma + beta
+ * -- BertSelfOutput / BertOutput (4.38.2) with the dense bias already added by the GEMM,
+ * and predictor.layer_norm (structure_model/model.py:152).  residual may be NULL.
+ * H must be 256, 512, 768 or 1024. */
+int e3d_residual_layernorm_fwd(const float* x, const float* residual, const float* gamma,
+                               const float* beta, float eps, float* out, int M, int H,
+                               void* stream);
+
+/* SELayer gated branch (structure_model/model.py:61-67):
+ *   out = x + gate * (LayerNorm_1e-5_noaffine(y) * (1 + scale) + shift)
+ * mod is the adaLN_modulation output [Mc, 6H]; (shift,scale,gate) are chunks
+ * (3*branch, 3*branch+1, 3*branch+2) with branch 0 = msa, 1 = mlp.  Row m of x uses row
+ * m / rows_per_cond of mod (rows_per_cond = L when c is [B,1,H], 1 when c is [B,L,H]). */
+int e3d_adaln_gate_fwd(const float* x, const float* y, const float* mod, int branch,
+                       int rows_per_cond, float* out, int M, int H, void* stream);
+
+/* BertEmbeddings (structure_model/model.py:111-118, eval):
+ *   out[M,H] = LayerNorm_eps(x[M,F] @ W[H,F]^T + b) * gamma + beta (+ post_add[m / rows_per_add])
+ * post_add ([M / rows_per_add, H], may be NULL) is the timestep embedding the sequence model
+ * adds after the embedding (sequence_model/model.py:213,220).  F <= 32. */
+int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, const float* b,
+                            const float* gamma, const float* beta, float eps,
+                            const float* post_add, int rows_per_add, float* out, int M, int H,
+                            void* stream);
+
+/* predictor.dense2 (structure_model/model.py:153): out[M,Nout] = x[M,H] @ W[Nout,H]^T + b,
+ * Nout <= 32 (8 angles / 20 amino-acid logits). */
+int e3d_head_linear_fwd(const float* x, const float* W, const float* b, float* out, int M,
+                        int H, int Nout, void* stream);
+
+/* One DDPM ancestral update (+ wrap) (structure_model/sample.py:90-99,140-142 and
+ * utils.py:20-40):  mean = sqrt_recip_alpha * (x - beta * eps_hat / sqrt_one_minus_ab)
+ *   v = mean + sigma * noise   (noise == NULL or sigma == 0: no noise term)
+ *   out = wrap ? wrap_[-pi,pi)(v) : v          (p_sample_loop wraps, bare p_sample does not)
+ * n = number of elements. */
+int e3d_ddpm_step_wrap(const float* x, const float* eps_hat, const float* noise,
+                       float sqrt_recip_alpha, float beta, float sqrt_one_minus_ab, float sigma,
+                       int wrap, float* out, int64_t n, void* stream);
+
+/* Forward noising q(x_t | x_0) with wrap (structure_model/dataset.py:211-228):
+ *   out[b] = wrap(sqrt_ab[t[b]] * x0[b] + sqrt_1mab[t[b]] * noise[b]),  per = elements per item. */
+int e3d_q_sample_wrap(const float* x0, const float* noise, const int64_t* t,
+                      const float* sqrt_ab, const float* sqrt_1mab, float* out, int B,
+                      int64_t per, void* stream);
+
+/* Discrete reverse step p(z_s | z_t) (sequence_model/sample.py:120-179), C = 20 classes:
+ *   prob[n,:] = normalise( sum_x0 softmax(logits[n])[x0] * (Qt[b]^T[xt,:] * Qsb[b][x0,:]) / Qtb[b][x0,xt] )
+ * with Qt = rownorm(Qsb/Qtb) computed in-kernel; x_t given as class indices [B*L] (int32; the
+ * reference carries one-hots).  mode 0: argmax (diverse=False); mode 1: inverse-CDF draw with
+ * uniforms u[B*L] (diverse=True).  Writes class index out_idx[B*L] and, if prob_out != NULL,
+ * prob [B*L,C]. */
+int e3d_discrete_posterior_sample(const int32_t* xt_idx, const float* logits, const float* Qsb,
+                                  const float* Qtb, const float* u, int mode, int32_t* out_idx,
+                                  float* prob_out, int B, int L, int C, void* stream);
+
+/* Forward discrete noising (sequence_model/model.py:291-311): prob[n,:] = Qtb[b][:, x0[n]];
+ * x0 index < 0 marks a padding (all-zero one-hot) row -> class 0.  u as above. */
+int e3d_discrete_q_sample(const int32_t* x0_idx, const float* Qtb, const float* u, int mode,
+                          int32_t* out_idx, int B, int L, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3D_HIP_H */

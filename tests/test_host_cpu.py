@@ -1,0 +1,152 @@
+"""CPU: the product's host logic (schedules, datasets, checkpoint keys, entry-point plumbing)
+against the reference-generated fixtures, and the C-ABI library's load/exports (no compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, seeded_state_dict, synthetic_pockets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+
+
+# ------------------------------------------------------------------------------- C-ABI
+def test_library_loads_and_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "e3d_hip.h")).read()
+    declared = set(re.findall(r"\b(e3d_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pkg.hip.EXPORTS), declared ^ set(pkg.hip.EXPORTS)
+    lib = pkg.hip.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.e3d_abi_version() == pkg.hip.ABI_VERSION
+    # argument validation happens before any launch: callable without a GPU
+    assert lib.e3d_gemm_bias_act_f32(None, 0, None, None, None, 0, 1, 128, 32, 0, None) < 0
+    assert b"null pointer" in lib.e3d_last_error()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg_dir = os.path.join(ROOT, "e3-invaraint-diffusion-model_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_cpu_inputs_fail_loudly(pkg):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=1,
+             max_position_embeddings=16)
+    m = ConditionalBertForDiffusionBase(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), 8)
+    pk = synthetic_pockets(1, 16, seed=0, lig_range=(3, 9), rec_range=(6, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, dtype=torch.long), torch.zeros(1, 16, 8), pk["ligand_attn_mask"], pk["receptor_seq"],
+          pk["receptor_angles"], pk["receptor_attn_mask"])
+
+
+# ------------------------------------------------------------------------------- structure host side
+def test_structure_utils_bit_exact(pkg):
+    from e3diff_amd.structure_model import utils as U
+    fx = load("structure_utils.pt")
+    for T in (50, 1000):
+        got = U.compute_alphas(U.cosine_beta_schedule(T))
+        assert set(got) == set(fx[f"alphas_T{T}"])
+        for k, v in fx[f"alphas_T{T}"].items():
+            assert torch.equal(got[k], v), (T, k)
+        tab = U.CosineTables(T)
+        assert torch.equal(tab.sqrt_recip_alphas, 1.0 / torch.sqrt(fx[f"alphas_T{T}"]["alphas"]))
+    assert torch.equal(U.modulo_with_wrapped_range(fx["wrap_in"]), fx["wrap_out"])
+    assert U.modulo_with_wrapped_range(3, -2, 2) == -1
+    a, b = fx["loss_in"]
+    assert torch.equal(U.radian_l1_loss(a, b), fx["radian_l1"])
+    assert torch.equal(U.radian_smooth_l1_loss(a, b, beta=torch.pi / 10), fx["radian_smooth_l1_b0.314"])
+    assert torch.equal(U.radian_smooth_l1_loss(torch.tensor(-17.0466), torch.tensor(-1.3888), beta=0.1), fx["doc_smooth"])
+    assert U.tolerant_comparison_check(-3.1415927410125732, ">=", -np.pi) is True    # utils.py:115-116
+    assert U.tolerant_comparison_check([0.5, 4.0], "<=", np.pi) is False
+
+
+def test_structure_checkpoint_keys_match_reference(pkg):
+    """state_dict keys/shapes == the reference's (fixture 'shapes' came from the reference model
+    under transformers 5.15, i.e. without distance_embedding) + the 4.38.2 rel-key tables."""
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion
+    fx = load("structure_forward_tiny.pt")
+    cfg = fx["cfg"]
+    c = dict(hidden_size=cfg["hidden_size"], num_attention_heads=cfg["num_heads"],
+             intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+             max_position_embeddings=cfg["max_seq_len"])
+    m = ConditionalBertForDiffusion(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True),
+                                    feature_names=list("abcdefgh"), loss_func=[])
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    extra = {k for k in shapes if k not in fx["shapes"]}
+    assert {k: v for k, v in shapes.items() if k not in extra} == fx["shapes"]
+    assert extra and all(k.endswith("self.distance_embedding.weight") for k in extra)
+    P = cfg["max_seq_len"]
+    assert all(shapes[k] == (2 * P - 1, 64) for k in extra)
+    # 2 SELayers + 2 enc + 2 dec self-attentions carry a table; cross-attentions do not
+    assert len(extra) == 2 + 2 * cfg["num_hidden_layers"]
+    assert not any("crossattention" in k for k in extra)
+    # SELayer.adaLN_modulation[0] starts at zero (model.py:50-51)
+    assert float(m.receptor_emb.adaLN_modulation[0].weight.abs().sum()) == 0.0
+
+
+def test_structure_dataset_layout_matches_reference(pkg):
+    from e3diff_amd.structure_model.dataset import LigandBindingSiteDataset, NoisedAnglesDataset
+    fx = load("structure_dataset.pt")
+    ds = LigandBindingSiteDataset(None, "train", max_len=32, pocket_ext=1, records=fx["records"])
+    assert len(ds) == fx["n_train"]
+    for split, n in fx["split_sizes"].items():
+        assert len(LigandBindingSiteDataset(None, split, 32, 1, records=fx["records"])) == n
+    item = ds[0]
+    assert item["structure_ids"] == fx["item0_ids"]
+    assert set(item) - {"structure_ids"} == set(fx["item0"])
+    for k, v in fx["item0"].items():
+        if torch.is_tensor(v):
+            assert torch.equal(item[k], v) and item[k].dtype == v.dtype, k
+        else:
+            assert item[k] == v, k
+    nds = NoisedAnglesDataset(ds, timesteps=100)
+    real = torch.randn_like
+    torch.randn_like = lambda x, **k: fx["injected_randn"]
+    try:
+        nitem = nds.__getitem__(1, use_timestep=37)
+    finally:
+        torch.randn_like = real
+    for k, v in fx["noised_item1"].items():
+        if torch.is_tensor(v):
+            assert torch.equal(nitem[k], v), k
+    with pytest.raises(RuntimeError, match="Length exceed"):
+        LigandBindingSiteDataset(None, "train", max_len=4, pocket_ext=1, records=fx["records"])[0]
+    with pytest.raises(IndexError):
+        ds[len(ds)]
+
+
+def test_structure_loss_terms_match_reference(pkg):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion
+    fx = load("structure_forward_tiny.pt")
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=1,
+             max_position_embeddings=16)
+    m = ConditionalBertForDiffusion(
+        BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("abcdefgh"),
+        loss_func=[ConditionalBertForDiffusion.diheral_loss_func] * 4 + [ConditionalBertForDiffusion.angle_loss_func] * 4,
+        epochs=350, lr_scheduler="LinearWarmup", l2_lambda=0.1)
+    got = m.loss_terms_from_prediction(fx["loss_pred"], fx["known_noise"], fx["pockets"]["ligand_attn_mask"])
+    assert torch.allclose(got, fx["loss_terms"], rtol=1e-6, atol=1e-7)
+    opt = m.configure_optimizers()
+    assert isinstance(opt["optimizer"], torch.optim.AdamW) and opt["lr_scheduler"]["interval"] == "epoch"
+    sch = opt["lr_scheduler"]["scheduler"]
+    lrs = []
+    for _ in range(40):
+        lrs.append(sch.get_last_lr()[0])
+        opt["optimizer"].step()
+        sch.step()
+    assert lrs[0] == 0.0 and lrs[35] == pytest.approx(5e-5) and lrs[36] < 5e-5     # warm-up = 10 % of 350 epochs

@@ -1,0 +1,254 @@
+"""GPU parity of each HIP kernel (through the C-ABI via ops.py) against the CPU oracle / a plain
+fp32 torch CPU statement of the same op.  Tolerance: the north star's 1e-4 relative fp32 (most
+kernels are far tighter; the bound asserted is written per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+from oracle import bert as obert, sequence as oseq, structure as ostr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (130, 256, 64), (257, 768, 768), (1000, 1024, 3072),
+                                   (64, 4608, 768), (4096, 2304, 768)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_bias_act(pkg, hip, M, N, K, act):
+    a = torch.randn(M, K, generator=g(M + N))
+    w = torch.randn(N, K, generator=g(K)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(7))
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = {0: lambda x: x, 1: F.gelu, 2: F.silu}[act](ref).float()
+    got = pkg.ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), act)
+    assert rel_err(got, ref) < 5e-6
+
+
+def test_gemm_strided_input_and_no_bias(pkg, hip):
+    a = torch.randn(300, 3 * 256, generator=g(1))
+    w = torch.randn(128, 256, generator=g(2)) / 16
+    got = pkg.ops.gemm(a.to(DEV)[:, 256:512], w.to(DEV), None)
+    assert rel_err(got, a[:, 256:512] @ w.t()) < 5e-6
+
+
+def test_gemm_rejects_bad_shapes(pkg, hip):
+    a, w = torch.zeros(4, 48, device=DEV), torch.zeros(100, 48, device=DEV)
+    with pytest.raises(RuntimeError, match="N%128"):
+        pkg.ops.gemm(a, w)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        pkg.ops.gemm(a.cpu(), w)
+
+
+# ------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, mask, E, P):
+    """q,k,v [B,nh,L,64] fp64 statement of SURVEY App. A eq. (1)-(4)."""
+    s = q @ k.transpose(-1, -2)
+    if E is not None:
+        s = s + obert.relkey_scores_literal(q, E, P)
+    s = s / 8.0
+    if mask is not None:
+        s = s + ((1.0 - mask) * -10000.0)[:, None, None, :]
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("B,nh,L,P", [(2, 4, 16, 16), (1, 12, 64, 64), (3, 2, 50, 64), (2, 12, 128, 128),
+                                      (1, 3, 256, 256), (2, 1, 33, 40)])
+@pytest.mark.parametrize("relkey", [True, False])
+def test_attention_self(pkg, hip, B, nh, L, P, relkey):
+    H = nh * 64
+    qkv = torch.randn(B * L, 3 * H, generator=g(L))
+    E = torch.randn(2 * P - 1, 64, generator=g(P + 1)) if relkey else None
+    lens = torch.randint(1, L + 1, (B,), generator=g(3))
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    dq = qkv.to(DEV)
+    got, lse = pkg.ops.attention(dq[:, :H], dq[:, H:2 * H], dq[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),
+                                 dist_emb=None if E is None else E.to(DEV), max_pos=P, want_lse=True)
+    split = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
+    q, k, v = split(qkv[:, :H]), split(qkv[:, H:2 * H]), split(qkv[:, 2 * H:])
+    ref = ref_attention(q, k, v, mask.double(), None if E is None else E.double(), P)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * L, H).float()
+    assert rel_err(got, ref) < 1e-5
+    s = q @ k.transpose(-1, -2)
+    if E is not None:
+        s = s + obert.relkey_scores_literal(q, E.double(), P)
+    s = s / 8.0 + ((1.0 - mask.double()) * -10000.0)[:, None, None, :]
+    assert rel_err(lse, torch.logsumexp(s, -1).float()) < 1e-5
+
+
+def test_attention_cross_rectangular_and_nomask(pkg, hip):
+    B, nh, Lq, Lk = 2, 3, 40, 70
+    H = nh * 64
+    qb = torch.randn(B * Lq, H, generator=g(1))
+    kv = torch.randn(B * Lk, 2 * H, generator=g(2))
+    dkv = kv.to(DEV)
+    got = pkg.ops.attention(qb.to(DEV), dkv[:, :H], dkv[:, H:], B, nh, Lq, Lk)
+    sp = lambda x, L: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
+    ref = ref_attention(sp(qb, Lq), sp(kv[:, :H], Lk), sp(kv[:, H:], Lk), None, None, 0)
+    assert rel_err(got, ref.permute(0, 2, 1, 3).reshape(B * Lq, H).float()) < 1e-5
+
+
+def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):
+    """An all-zero key mask adds -10000 to every key: softmax is unchanged (uniform shift)."""
+    B, nh, L = 1, 1, 32
+    qkv = torch.randn(L, 192, generator=g(5))
+    d = qkv.to(DEV)
+    a = pkg.ops.attention(d[:, :64], d[:, 64:128], d[:, 128:], B, nh, L, L, key_mask=torch.zeros(1, L, device=DEV))
+    b = pkg.ops.attention(d[:, :64], d[:, 64:128], d[:, 128:], B, nh, L, L, key_mask=torch.ones(1, L, device=DEV))
+    assert rel_err(a, b) < 1e-5
+
+
+def test_attention_rejects_relkey_longer_than_table(pkg, hip):
+    d = torch.zeros(80, 192, device=DEV)
+    with pytest.raises(RuntimeError, match="relative_key"):
+        pkg.ops.attention(d[:, :64], d[:, 64:128], d[:, 128:], 1, 1, 80, 80,
+                          dist_emb=torch.zeros(127, 64, device=DEV), max_pos=64)
+
+
+# ------------------------------------------------------------------------------------- row ops
+@pytest.mark.parametrize("H", [256, 512, 768, 1024])
+@pytest.mark.parametrize("M", [1, 5, 1030])
+def test_residual_layernorm(pkg, hip, H, M):
+    x, r = torch.randn(M, H, generator=g(H)) * 3, torch.randn(M, H, generator=g(M))
+    ga, be = 1 + 0.1 * torch.randn(H, generator=g(1)), torch.randn(H, generator=g(2))
+    ref = F.layer_norm((x + r).double(), (H,), ga.double(), be.double(), 1e-12).float()
+    got = pkg.ops.residual_layernorm(x.to(DEV), r.to(DEV), ga.to(DEV), be.to(DEV), 1e-12)
+    assert rel_err(got, ref) < 2e-6
+    got = pkg.ops.residual_layernorm(x.to(DEV), None, ga.to(DEV), be.to(DEV), 1e-12)
+    assert rel_err(got, F.layer_norm(x.double(), (H,), ga.double(), be.double(), 1e-12).float()) < 2e-6
+
+
+@pytest.mark.parametrize("rows_per_cond", [1, 16])
+@pytest.mark.parametrize("branch", [0, 1])
+def test_adaln_gate(pkg, hip, rows_per_cond, branch):
+    B, L, H = 3, 16, 768
+    M = B * L
+    x, y = torch.randn(M, H, generator=g(1)), torch.randn(M, H, generator=g(2)) * 2
+    mod = torch.randn(M // rows_per_cond, 6 * H, generator=g(3))
+    sh, sc, ga = [mod[:, (3 * branch + i) * H:(3 * branch + i + 1) * H].repeat_interleave(rows_per_cond, 0)
+                  for i in range(3)]
+    ref = x + ga * (F.layer_norm(y, (H,)) * (1 + sc) + sh)
+    got = pkg.ops.adaln_gate(x.to(DEV), y.to(DEV), mod.to(DEV), branch, rows_per_cond)
+    assert rel_err(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("Fin,H", [(8, 768), (20, 768), (20, 256)])
+def test_embed_layernorm(pkg, hip, Fin, H):
+    M, L = 48, 16
+    x = torch.randn(M, Fin, generator=g(1))
+    w, b = torch.randn(H, Fin, generator=g(2)), torch.randn(H, generator=g(3))
+    ga, be = 1 + 0.1 * torch.randn(H, generator=g(4)), torch.randn(H, generator=g(5))
+    add = torch.randn(M // L, H, generator=g(6))
+    ref = F.layer_norm(F.linear(x, w, b), (H,), ga, be, 1e-12)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    assert rel_err(pkg.ops.embed_layernorm(d(x), d(w), d(b), d(ga), d(be), 1e-12), ref) < 2e-6
+    got = pkg.ops.embed_layernorm(d(x), d(w), d(b), d(ga), d(be), 1e-12, d(add), L)
+    assert rel_err(got, ref + add.repeat_interleave(L, 0)) < 2e-6
+
+
+@pytest.mark.parametrize("n_out", [8, 20])
+def test_head_linear(pkg, hip, n_out):
+    x = torch.randn(77, 768, generator=g(1))
+    w, b = torch.randn(n_out, 768, generator=g(2)) / 27, torch.randn(n_out, generator=g(3))
+    got = pkg.ops.head_linear(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert rel_err(got, F.linear(x.double(), w.double(), b.double()).float()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------- samplers
+def test_ddpm_step_wrap_bit_exact_vs_oracle(pkg, hip):
+    T = 1000
+    tab = ostr.compute_alphas(ostr.cosine_beta_schedule(T))
+    x = ostr.modulo_with_wrapped_range(torch.randn(5, 33, 8, generator=g(1)) * 2)
+    eps, noise = torch.randn(5, 33, 8, generator=g(2)), torch.randn(5, 33, 8, generator=g(3))
+    for t in (0, 1, 500, 999):
+        const = lambda t, x, *a: eps  # noqa: E731
+        want = ostr.p_sample(const, None, x, None, None, None, torch.full((5,), t), tab["betas"], noise)
+        args = (float(1.0 / torch.sqrt(tab["alphas"][t])), float(tab["betas"][t]),
+                float(tab["sqrt_one_minus_alphas_cumprod"][t]),
+                0.0 if t == 0 else float(torch.sqrt(tab["posterior_variance"][t])))
+        got = pkg.ops.ddpm_step_wrap(x.to(DEV), eps.to(DEV), noise.to(DEV), *args, wrap=False).cpu()
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), t
+        got_w = pkg.ops.ddpm_step_wrap(x.to(DEV), eps.to(DEV), noise.to(DEV), *args, wrap=True).cpu()
+        d = ostr.modulo_with_wrapped_range(got_w - ostr.modulo_with_wrapped_range(want)).abs().max()
+        assert d < 1e-5 and got_w.min() >= -math.pi - 1e-6 and got_w.max() < math.pi + 1e-6
+
+
+def test_wrap_kernel_edge_values(pkg, hip):
+    v = torch.tensor([3.0, -3.0, 0.0, math.pi, -math.pi, 7.5, -7.5, 100.0, -100.0, 3.1415927410125732,
+                      -3.1415927410125732, 1e-8])
+    z = torch.zeros_like(v)
+    got = pkg.ops.ddpm_step_wrap(v.to(DEV), z.to(DEV), None, 1.0, 0.0, 1.0, 0.0, wrap=True).cpu()
+    assert torch.equal(got, ostr.modulo_with_wrapped_range(v))     # bit-exact incl. the +-pi edges
+
+
+def test_q_sample_wrap(pkg, hip):
+    T = 100
+    tab = ostr.compute_alphas(ostr.cosine_beta_schedule(T))
+    x0 = ostr.modulo_with_wrapped_range(torch.randn(6, 16, 8, generator=g(1)) * 2)
+    noise = ostr.modulo_with_wrapped_range(torch.randn(6, 16, 8, generator=g(2)))
+    t = torch.tensor([0, 5, 37, 50, 98, 99])
+    want = torch.stack([ostr.add_noise_by_timestep(x0[i], int(t[i]), tab, noise[i]) for i in range(6)])
+    got = pkg.ops.q_sample_wrap(x0.to(DEV), noise.to(DEV), t.to(DEV), tab["sqrt_alphas_cumprod"].to(DEV),
+                                tab["sqrt_one_minus_alphas_cumprod"].to(DEV)).cpu()
+    assert ostr.modulo_with_wrapped_range(got - want).abs().max() < 2e-6
+
+
+def _blosum():
+    import os
+    from helpers import GOLDEN
+    return torch.load(os.path.join(GOLDEN, "blosum_substitute.pt"), weights_only=True)
+
+
+@pytest.mark.parametrize("trans_name", ["blosum", "uniform"])
+def test_discrete_posterior_sample(pkg, hip, trans_name):
+    B, L, C, T = 4, 37, 20, 50
+    sched = oseq.NoiseScheduleDiscrete(T)
+    trans = oseq.BlosumTransition(_blosum()) if trans_name == "blosum" else oseq.UniformTransition(C)
+    xt_idx = torch.randint(0, C, (B, L), generator=g(1))
+    x_t = F.one_hot(xt_idx, C).float()
+    logits = torch.randn(B, L, C, generator=g(2)) * 2
+    u = torch.rand(B, L, generator=g(3))
+    for s_int in (1, 24, 48):
+        s = s_int * torch.ones(B, 1) / T
+        t = (s_int + 1) * torch.ones(B, 1) / T
+        prob = oseq.reverse_prob(t, s, x_t, logits, sched, trans)
+        qtb = trans.get_Qt_bar(sched.get_alpha_bar(t)).to(DEV)
+        qsb = trans.get_Qt_bar(sched.get_alpha_bar(s)).to(DEV)
+        idx, p = pkg.ops.discrete_posterior_sample(xt_idx.int().to(DEV), logits.to(DEV), qsb, qtb, None, True)
+        assert rel_err(p.reshape(-1, C), prob) < 1e-5
+        # argmax: identical wherever the oracle's top-2 gap exceeds the fp tolerance
+        top2 = prob.topk(2, -1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+        assert torch.equal(idx.cpu().reshape(-1).long()[clear], prob.argmax(-1)[clear])
+        idx_u = pkg.ops.discrete_posterior_sample(xt_idx.int().to(DEV), logits.to(DEV), qsb, qtb, u.to(DEV))
+        want_u = oseq.categorical_from_uniform(prob, u.reshape(-1))
+        cdf = prob.cumsum(-1)
+        clear = ((cdf - (u.reshape(-1, 1) * cdf[:, -1:])).abs().min(-1).values) > 1e-5
+        assert torch.equal(idx_u.cpu().reshape(-1).long()[clear], want_u[clear])
+        assert clear.float().mean() > 0.99
+
+
+def test_discrete_q_sample(pkg, hip):
+    B, L, C, T = 3, 16, 20, 50
+    sched, trans = oseq.NoiseScheduleDiscrete(T), oseq.BlosumTransition(_blosum())
+    x0 = torch.randint(0, C, (B, L), generator=g(1))
+    x0[:, 10:] = -1                                        # padding rows
+    onehot = F.one_hot(x0.clamp_min(0), C).float() * (x0 >= 0)[..., None]
+    t_int = torch.tensor([[3.0], [25.0], [50.0]])
+    u = torch.rand(B, L, generator=g(2))
+    qtb = trans.get_Qt_bar(sched.get_alpha_bar(t_int / T)).to(DEV)
+    want = oseq.apply_aa_noise(onehot, t_int, sched, trans, u=u).argmax(-1)
+    got = pkg.ops.discrete_q_sample(x0.int().to(DEV), qtb, u.to(DEV)).cpu().long()
+    prob = oseq.aa_noise_prob(onehot, t_int, sched, trans)
+    cdf = prob.cumsum(-1)
+    clear = ((cdf - (u.reshape(-1, 1) * cdf[:, -1:])).abs().min(-1).values > 1e-6) | (prob.sum(-1) == 0)
+    assert torch.equal(got.reshape(-1)[clear], want.reshape(-1)[clear])
+    assert bool((got[:, 10:] == 0).all())

@@ -1,0 +1,151 @@
+"""GPU parity of the structure model's denoising path (HIP, via the C-ABI) against (1) the
+reference-generated golden fixtures and (2) the CPU oracle on the same seeded inputs.
+Tolerance: 1e-4 relative fp32 on predicted noise/angles (BASELINE.json north_star)."""
+import os
+
+import pytest
+import torch
+
+from helpers import FULL_STRUCT, GOLDEN, rel_err, seeded_state_dict, synthetic_pockets
+from oracle import structure as ostr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def build(pkg, cfg, L, seed, zero_relkey=False, relkey=True):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
+    common = dict(hidden_size=cfg["hidden_size"], num_attention_heads=cfg["num_heads"],
+                  intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+                  max_position_embeddings=L,
+                  position_embedding_type="relative_key" if relkey else "absolute")
+    model = ConditionalBertForDiffusionBase(BertConfig(**common),
+                                            BertConfig(**common, is_decoder=True, add_cross_attention=True), 8)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = seeded_state_dict(shapes, seed=seed, zero_relkey=zero_relkey)
+    model.load_state_dict(sd, strict=True)
+    return model.eval().to(DEV), sd
+
+
+def to_dev(d):
+    return {k: v.to(DEV) for k, v in d.items() if torch.is_tensor(v)}
+
+
+def test_forward_matches_reference_golden(pkg, hip):
+    """The fixture was produced by the reference itself (transformers 5.15 => no relative_key
+    parameters): load exactly its state_dict into the product built without the rel-key term."""
+    fx = torch.load(os.path.join(GOLDEN, "structure_forward_tiny.pt"), weights_only=False)
+    cfg = dict(fx["cfg"])
+    model, sd = build(pkg, cfg, cfg["max_seq_len"], fx["seed"], relkey=False)
+    assert set(sd) == set(fx["shapes"])           # checkpoint keys == the reference's
+    model.load_state_dict(seeded_state_dict(fx["shapes"], seed=fx["seed"]), strict=True)
+    pk = to_dev(fx["pockets"])
+    for tag, (t, want) in fx["outs"].items():
+        got = model(t.to(DEV), fx["x_t"].to(DEV), pk["ligand_attn_mask"], pk["receptor_seq"],
+                    pk["receptor_angles"], pk["receptor_attn_mask"])
+        assert rel_err(got, want) < TOL, tag
+
+
+def test_sampler_matches_reference_golden(pkg, hip):
+    from e3diff_amd.structure_model.sample import p_sample_loop
+    fx = torch.load(os.path.join(GOLDEN, "structure_forward_tiny.pt"), weights_only=False)
+    sx = torch.load(os.path.join(GOLDEN, "structure_sampler_tiny.pt"), weights_only=False)
+    cfg = dict(fx["cfg"])
+    model, _ = build(pkg, cfg, cfg["max_seq_len"], fx["seed"], relkey=False)
+    model.load_state_dict(seeded_state_dict(fx["shapes"], seed=fx["seed"]), strict=True)
+    pk = to_dev(fx["pockets"])
+    traj = p_sample_loop(model, pk["ligand_attn_mask"], sx["x_T"].to(DEV), pk["receptor_seq"],
+                         pk["receptor_attn_mask"], pk["receptor_angles"], sx["T"],
+                         ostr.cosine_beta_schedule(sx["T"]), disable_pbar=True, noises=sx["noises"].to(DEV), step=1)
+    assert traj.shape == sx["traj"].shape and traj.device.type == "cpu"
+    assert ostr.modulo_with_wrapped_range(traj - sx["traj"]).abs().max().item() < TOL * 3.1416
+
+
+@pytest.mark.parametrize("layers,B,L", [(2, 3, 64), (12, 2, 128), (1, 2, 256), (2, 5, 50)])
+def test_forward_matches_oracle_full_width_with_relkey(pkg, hip, layers, B, L):
+    cfg = dict(FULL_STRUCT, num_hidden_layers=layers)
+    model, sd = build(pkg, cfg, max(L, 64), seed=100 + layers)
+    ocfg = {"num_heads": 12, "max_pos": max(L, 64)}
+    pk = synthetic_pockets(B, L, seed=L)
+    x_t = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=torch.Generator().manual_seed(1)))
+    for t in (torch.full((B,), 999), torch.randint(0, 1000, (B, 1), generator=torch.Generator().manual_seed(2))):
+        want = ostr.forward(sd, ocfg, t, x_t, pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"],
+                            pk["receptor_attn_mask"])
+        d = to_dev(pk)
+        got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
+                    d["receptor_attn_mask"])
+        assert got.shape == (B, L, 8)
+        assert rel_err(got, want) < TOL
+
+
+def test_cached_receptor_path_is_identical(pkg, hip):
+    """encode_receptor once + decode == forward (the sampler's F5 restructuring changes nothing)."""
+    cfg = dict(FULL_STRUCT, num_hidden_layers=2)
+    model, _ = build(pkg, cfg, 64, seed=5)
+    d = to_dev(synthetic_pockets(4, 64, seed=9))
+    x_t = torch.randn(4, 64, 8, device=DEV)
+    t = torch.full((4,), 17, device=DEV)
+    a = model(t, x_t, d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+    rec = model.encode_receptor(d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+    b = model.decode(t, x_t, d["ligand_attn_mask"], rec)
+    assert torch.equal(a, b)
+
+
+def test_sampling_loop_matches_oracle_and_properties(pkg, hip):
+    from e3diff_amd.structure_model.sample import p_sample, p_sample_loop
+    cfg = dict(FULL_STRUCT, num_hidden_layers=2)
+    L, B, T = 64, 2, 5
+    model, sd = build(pkg, cfg, L, seed=7)
+    ocfg = {"num_heads": 12, "max_pos": L}
+    pk = synthetic_pockets(B, L, seed=4)
+    gen = torch.Generator().manual_seed(3)
+    x_T = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=gen))
+    noises = torch.randn(T, B, L, 8, generator=gen)
+    betas = ostr.cosine_beta_schedule(T)
+    fn = lambda t, x, lm, rs, ra, rm: ostr.forward(sd, ocfg, t, x, lm, rs, ra, rm)  # noqa: E731
+    want = ostr.p_sample_loop(fn, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"],
+                              pk["receptor_angles"], T, betas, noises=noises)
+    d = to_dev(pk)
+    got = p_sample_loop(model, d["ligand_attn_mask"], x_T.to(DEV), d["receptor_seq"], d["receptor_attn_mask"],
+                        d["receptor_angles"], T, betas, disable_pbar=True, noises=noises.to(DEV), step=1)
+    assert ostr.modulo_with_wrapped_range(got - want).abs().max().item() < TOL * 3.1416
+    assert got.min() >= -3.1416 and got.max() <= 3.1416            # every step is wrapped
+    # single un-wrapped step, tensor timestep, own RNG at t == 0 (no noise)
+    one = p_sample(model, d["ligand_attn_mask"], x_T.to(DEV), d["receptor_seq"], d["receptor_attn_mask"],
+                   d["receptor_angles"], torch.zeros(B, dtype=torch.long, device=DEV), betas)
+    want1 = ostr.p_sample(fn, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"],
+                          pk["receptor_angles"], torch.zeros(B, dtype=torch.long), betas)
+    assert rel_err(one, want1) < TOL
+    with pytest.raises(AssertionError, match="multiple values"):
+        p_sample(model, d["ligand_attn_mask"], x_T.to(DEV), d["receptor_seq"], d["receptor_attn_mask"],
+                 d["receptor_angles"], torch.tensor([1, 2], device=DEV), betas)
+
+
+def test_padding_keys_do_not_leak(pkg, hip):
+    """Changing receptor/ligand values at padded positions must not change real-position outputs."""
+    cfg = dict(FULL_STRUCT, num_hidden_layers=1)
+    model, _ = build(pkg, cfg, 64, seed=8)
+    pk = synthetic_pockets(2, 64, seed=6)
+    d = to_dev(pk)
+    x_t = torch.randn(2, 64, 8, device=DEV)
+    t = torch.full((2,), 3, device=DEV)
+    a = model(t, x_t, d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+    ra = d["receptor_angles"] + (1 - d["receptor_attn_mask"])[..., None] * 5.0
+    xt2 = x_t + (1 - d["ligand_attn_mask"])[..., None] * 5.0
+    b = model(t, xt2, d["ligand_attn_mask"], d["receptor_seq"], ra, d["receptor_attn_mask"])
+    m = d["ligand_attn_mask"].bool()
+    assert rel_err(a[m], b[m]) < 1e-5
+
+
+def test_cpu_inputs_fail_loudly(pkg):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=1,
+             max_position_embeddings=16)
+    m = ConditionalBertForDiffusionBase(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), 8)
+    pk = synthetic_pockets(1, 16, seed=0, lig_range=(3, 9), rec_range=(6, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, dtype=torch.long), torch.zeros(1, 16, 8), pk["ligand_attn_mask"], pk["receptor_seq"],
+          pk["receptor_angles"], pk["receptor_attn_mask"])
