@@ -45,6 +45,9 @@ def lib():
             raise HipExtensionMissing(
                 f"{LIB_PATH} not found: the HIP extension is the only compute path of this package "
                 "(no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+        # torch ships its own libamdhip64; import it FIRST so that this library binds to the same
+        # HIP runtime instance (two runtimes in one process do not share the device context).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the header and the .so disagree

@@ -11,6 +11,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Per-launch timing hook for bench.py: when TRACE is a list, timed launches append
+# (kernel name, start event, end event, meta) -- HIP events on the launch stream.
+TRACE = None
+
+
+class _timed:
+    def __init__(self, name, meta):
+        self.on = TRACE is not None
+        if self.on:
+            self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), meta)
+
+    def __enter__(self):
+        if self.on:
+            self.rec[1].record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec[2].record()
+            TRACE.append(self.rec)
+
+
 def _chk(t, name, dtype=torch.float32):
     if t is None:
         return
@@ -34,8 +55,9 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
-    hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
-                                              out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
+    with _timed("gemm", (M, N, K)):
+        hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
+                                                  out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
     return out
 
 
@@ -52,10 +74,11 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         assert dist_emb.is_contiguous() and dist_emb.shape == (2 * max_pos - 1, 64), dist_emb.shape
     out = torch.empty((B * Lq, nh * 64), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, nh, Lq), device=q.device, dtype=torch.float32) if want_lse else None
-    hip.check(hip.lib().e3d_relkey_attn_fwd(
-        _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
-        _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
-        B, nh, Lq, Lk, _stream()), "e3d_relkey_attn_fwd")
+    with _timed("attn_relkey" if dist_emb is not None else "attn_cross", (B, nh, Lq, Lk)):
+        hip.check(hip.lib().e3d_relkey_attn_fwd(
+            _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
+            _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
+            B, nh, Lq, Lk, _stream()), "e3d_relkey_attn_fwd")
     return (out, lse) if want_lse else out
 
 

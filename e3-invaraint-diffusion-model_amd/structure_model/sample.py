@@ -65,17 +65,17 @@ def _tables(betas):
 
 @torch.no_grad()
 def p_sample(model, ligand_mask, ligand_angle_noise, receptor_seq, receptor_mask, receptor_angle,
-             timestep, betas, noise=None, receptor_cache=None, out=None) -> torch.Tensor:
-    """One reverse step x_t -> x_{t-1} BEFORE the wrap-free return of the reference
-    (sample.py:55-99) -- here the wrap of p_sample_loop (sample.py:140-142) is NOT applied:
-    this function returns the unwrapped value like the reference's p_sample does.
+             timestep, betas, noise=None, receptor_cache=None, out=None, wrap=False) -> torch.Tensor:
+    """One reverse step x_t -> x_{t-1} (reference sample.py:55-99).  Like the reference's
+    p_sample the result is NOT wrapped unless ``wrap=True`` (p_sample_loop's sample.py:140-142
+    fused into the same kernel).
 
     ``timestep``: int64 [B] with one distinct value (asserted, as in the reference) or an int.
     ``betas``: the schedule betas [T] (any device) or a prebuilt CosineTables.
     ``noise``: optional injected N(0,1) draw (parity tests); default torch.randn_like on device.
     """
     return _reverse_step(model, ligand_mask, ligand_angle_noise, receptor_seq, receptor_mask,
-                         receptor_angle, timestep, betas, noise, receptor_cache, out, wrap=False)
+                         receptor_angle, timestep, betas, noise, receptor_cache, out, wrap=wrap)
 
 
 def _reverse_step(model, ligand_mask, x_t, receptor_seq, receptor_mask, receptor_angle, timestep,

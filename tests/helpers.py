@@ -83,3 +83,16 @@ def rel_err(a, b):
     """max |a-b| / max(|b|max, tiny): the "relative fp32" figure the tests assert on."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def reverse_step_tolerance(betas, t_index, eps_scale=1.0, rel=1e-4):
+    """Absolute tolerance for ONE reverse step x_t -> x_{t-1} given the north star's ``rel``
+    (1e-4 relative fp32) on the predicted noise.  The update is
+    sqrt(1/alpha_t) * (x_t - beta_t * eps / sqrt(1 - abar_t)), so an error d on eps is amplified by
+    sqrt(1/alpha_t) * beta_t / sqrt(1 - abar_t) -- x100 at t = T-1, where the cosine schedule's
+    beta is clipped to 0.9999 (structure_model/utils.py:18).  Free-running trajectories are
+    therefore compared step by step (teacher-forced), never end to end."""
+    alphas = 1.0 - betas
+    abar = torch.cumprod(alphas, 0)
+    amp = (1.0 / torch.sqrt(alphas[t_index])) * betas[t_index] / torch.sqrt(1.0 - abar[t_index])
+    return rel * eps_scale * float(amp) + 2e-5

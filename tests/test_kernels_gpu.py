@@ -97,13 +97,18 @@ def test_attention_cross_rectangular_and_nomask(pkg, hip):
 
 
 def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):
-    """An all-zero key mask adds -10000 to every key: softmax is unchanged (uniform shift)."""
+    """An all-zero key mask adds -10000 to every key in fp32, as the reference does: the softmax
+    is that of scores quantised to ulp(10000) ~ 1e-3, NOT -inf/NaN.  Checked against the same fp32
+    statement on the CPU; a one-ulp difference of a score moves a probability by ~1e-3, hence the
+    looser bound of this degenerate case."""
     B, nh, L = 1, 1, 32
     qkv = torch.randn(L, 192, generator=g(5))
     d = qkv.to(DEV)
     a = pkg.ops.attention(d[:, :64], d[:, 64:128], d[:, 128:], B, nh, L, L, key_mask=torch.zeros(1, L, device=DEV))
-    b = pkg.ops.attention(d[:, :64], d[:, 64:128], d[:, 128:], B, nh, L, L, key_mask=torch.ones(1, L, device=DEV))
-    assert rel_err(a, b) < 1e-5
+    q, k, v = qkv[:, :64], qkv[:, 64:128], qkv[:, 128:]
+    s = (q @ k.t()) / 8.0 + (1.0 - torch.zeros(1, L)) * -10000.0
+    assert torch.isfinite(a).all()
+    assert rel_err(a, torch.softmax(s, -1) @ v) < 5e-3
 
 
 def test_attention_rejects_relkey_longer_than_table(pkg, hip):
