@@ -150,3 +150,75 @@ def test_structure_loss_terms_match_reference(pkg):
         opt["optimizer"].step()
         sch.step()
     assert lrs[0] == 0.0 and lrs[35] == pytest.approx(5e-5) and lrs[36] < 5e-5     # warm-up = 10 % of 350 epochs
+
+
+# ------------------------------------------------------------------------------- sequence host side
+def test_sequence_utils_bit_exact(pkg):
+    from e3diff_amd.sequence_model import utils as U
+    fx = load("sequence_utils.pt")
+    sched = U.PredefinedNoiseScheduleDiscrete("cosine", 50)
+    assert torch.equal(sched.betas, fx["betas"]) and torch.equal(sched.alphas_bar, fx["alphas_bar"])
+    t_norm = (torch.arange(51).float() / 50).unsqueeze(1)
+    ab = sched.get_alpha_bar(t_normalized=t_norm)
+    assert torch.equal(ab, fx["alpha_bar_of_t"])
+    assert torch.equal(sched(t_normalized=t_norm), fx["betas"][torch.arange(51)].unsqueeze(1))
+    bl = U.BlosumTransition(x_classes=20)
+    assert torch.equal(bl.temperature_list, fx["blosum_temperature_501"])
+    assert torch.equal(bl.table_index(ab), fx["blosum_t_index"])
+    assert torch.equal(bl.table_index(fx["round_probe_in"]), fx["round_probe_idx"])      # round-half-even
+    assert torch.equal(bl.get_Qt_bar(ab, "cpu"), fx["blosum_Qtb"])
+    assert torch.equal(U.DiscreteUniformTransition(20).get_Qt_bar(ab, "cpu"), fx["uniform_Qtb"])
+    assert torch.equal(U.elbo_loss(*fx["elbo_in"]), fx["elbo"])
+    assert bl.get_Qt(ab, "cpu").shape == (51, 20, 20)
+    assert torch.allclose(U.DiscreteUniformTransition(20).get_Qt(torch.tensor([[0.25]]), "cpu").sum(-1),
+                          torch.ones(1, 20))
+
+
+def test_sequence_checkpoint_keys_and_init_match_reference(pkg):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    fx = load("sequence_forward_tiny.pt")
+    cfg = fx["cfg"]
+    c = dict(hidden_size=cfg["hidden_size"], num_attention_heads=cfg["num_heads"],
+             intermediate_size=cfg["intermediate_size"], num_hidden_layers=cfg["num_hidden_layers"],
+             max_position_embeddings=cfg["max_seq_len"])
+    m = PeptideDiff(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True),
+                    feature_names=list("ACDEFGHIKLMNPQRSTVWY"), loss_func=torch.nn.CrossEntropyLoss(),
+                    noise_schedule="cosine", timesteps=50, max_epochs=150, lr_scheduler="LinearWarmup")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    extra = {k for k in shapes if k not in fx["shapes"]}
+    assert {k: v for k, v in shapes.items() if k not in extra} == fx["shapes"]
+    assert extra and all(k.endswith("self.distance_embedding.weight") for k in extra)
+    assert any(k.startswith("receptor_feature_emb.") for k in shapes)        # dead weight kept (quirk)
+    sd = m.state_dict()
+    assert float(sd["decoder_normalize.adaLN_modulation.0.weight"].abs().sum()) == 0.0
+    assert float(sd["ligand_feature_emb.adaLN_modulation.0.weight"].abs().sum()) > 0.0   # xavier, model.py:183-198
+    assert float(sd["decoder.layer.0.output.dense.bias"].abs().sum()) == 0.0
+    assert m.configure_optimizers()["lr_scheduler"]["interval"] == "epoch"
+
+
+def test_sequence_dataset_adds_ligand_seq(pkg):
+    from e3diff_amd.sequence_model.dataset import LigandBindingSiteDataset
+    fx = load("structure_dataset.pt")
+    ds = LigandBindingSiteDataset(None, "train", max_len=32, pocket_ext=1, records=fx["records"])
+    item = ds[0]
+    assert ds.feature_names == list("ACDEFGHIKLMNPQRSTVWY")
+    assert item["ligand_seq"].shape == (32, 20)
+    n = int(item["ligand_length"])
+    assert bool((item["ligand_seq"][:n].sum(-1) == 1).all()) and float(item["ligand_seq"][n:].abs().sum()) == 0
+    for k, v in fx["item0"].items():
+        if torch.is_tensor(v):
+            assert torch.equal(item[k], v), k
+
+
+def test_load_generated_angles_roundtrip(pkg, tmp_path):
+    import pickle
+    from e3diff_amd.sequence_model.sample_by_generated_angles import load_generated_angles
+    arrs = [np.random.randn(7, 5, 8).astype(np.float32), np.random.randn(9, 8).astype(np.float32),
+            np.random.randn(3, 8).astype(np.float32)]
+    p = tmp_path / "out.pkl"
+    pickle.dump(arrs, open(p, "wb"))
+    chunks = load_generated_angles(str(p), max_seq_len=16, batch_size=2)
+    assert [c.shape for c in chunks] == [(2, 16, 8), (1, 16, 8)]
+    assert np.allclose(chunks[0][0, :5].numpy(), arrs[0][-1]) and float(chunks[0][0, 5:].abs().sum()) == 0
+    assert np.allclose(chunks[1][0, :3].numpy(), arrs[2])
