@@ -88,7 +88,9 @@ def test_transitions_on_device_bit_exact_index(pkg, hip):
     sched = PredefinedNoiseScheduleDiscrete("cosine", 50).to(DEV)
     t_norm = (torch.arange(51).float() / 50).unsqueeze(1).to(DEV)
     ab = sched.get_alpha_bar(t_normalized=t_norm)
-    assert torch.equal(ab.cpu(), fx["alpha_bar_of_t"])
+    # the alpha-bar table is exp(cumsum(log(.))) on the HOST: libm/SIMD width may differ in the last
+    # bit between the fixture's CPU and this box's, the integer index below may not
+    assert torch.allclose(ab.cpu(), fx["alpha_bar_of_t"], rtol=2e-6, atol=0)
     bl = BlosumTransition(x_classes=20)
     assert torch.equal(bl.table_index(ab).cpu(), fx["blosum_t_index"])          # INT index: bit-exact
     assert torch.equal(bl.table_index(fx["round_probe_in"].to(DEV)).cpu(), fx["round_probe_idx"])
