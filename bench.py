@@ -68,6 +68,19 @@ def build_model(L, device):
     return model.eval().to(device), pkg
 
 
+def host_cores():
+    """CPUs this process may actually use: the smaller of its affinity mask and its cgroup CPU
+    quota (the GPU box exposes 256 hardware threads but grants a 16-CPU share per GPU)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(L, seed):
     """Oracle (CPU restatement incl. the rel-key term) timed on the host cores: one full
     structure-model reverse step (forward + update + wrap) on a bounded sample of the workload."""
@@ -87,7 +100,7 @@ def cpu_baseline(L, seed):
     x = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8))
     betas = ostr.cosine_beta_schedule(1000)
     fn = lambda t, xx, lm, rs, ra, rm: ostr.forward(sd, cfg, t, xx, lm, rs, ra, rm)  # noqa: E731
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     torch.set_num_threads(cores)
     times = []
     with torch.no_grad():
@@ -97,6 +110,7 @@ def cpu_baseline(L, seed):
                 fn, pk["ligand_attn_mask"], x, pk["receptor_seq"], pk["receptor_attn_mask"],
                 pk["receptor_angles"], torch.full((B,), 999 - i), betas))
             times.append(time.perf_counter() - t0)
+            print(f"[cpu_baseline] step {i}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
     med = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": B / med, "unit": "pocket-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (CPU restatement of the reference incl. relative_key), structure model 12+12 layers, "
@@ -111,6 +125,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pockets per GPU")
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", default=os.environ.get("E3D_GEMM_MODE", "bf16x3"),
+                    choices=["f32", "bf16x3", "bf16x6"],
+                    help="GEMM arithmetic of the headline value (see DESIGN.md section 3)")
+    ap.add_argument("--only-default-mode", action="store_true", help="skip timing the other GEMM modes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,9 +177,19 @@ def main():
         barrier()
         return time.perf_counter() - t0
 
+    by_mode = {}
     with torch.no_grad():
+        # the other GEMM arithmetic modes, for transparency (same work, same kernels otherwise)
+        if not args.only_default_mode:
+            for mode in pkg.ops.GEMM_MODES:
+                if mode != args.gemm_mode:
+                    pkg.ops.set_gemm_mode(mode)
+                    timed(full_step, 1)
+                    by_mode[mode] = timed(full_step, max(1, args.steps // 2)) / max(1, args.steps // 2)
+        pkg.ops.set_gemm_mode(args.gemm_mode)
         timed(full_step, args.warmup)
         elapsed = timed(full_step, args.steps)
+        by_mode[args.gemm_mode] = elapsed / args.steps
         # the sampler's actual loop: receptor encoded once
         cache = model.encode_receptor(pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
 
@@ -178,10 +206,12 @@ def main():
         trace, pkg.ops.TRACE = pkg.ops.TRACE, None
     del cache
 
+    modes = sorted(by_mode)
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed_cached], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_cached] + [by_mode[m] for m in modes], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_cached = t.tolist()
+        elapsed, elapsed_cached, *rest = t.tolist()
+        by_mode = dict(zip(modes, rest))
 
     def avg_ms(name):
         d = [a.elapsed_time(b) for n, a, b, _ in trace if n == name]
@@ -197,6 +227,7 @@ def main():
         if os.path.exists(tj):
             traffic = json.load(open(tj)).get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
         a_tf = attn_flops(B, L) / (attn_ms * 1e-3) / 1e12
+        gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.gemm_mode]
         a_gb = attn_bytes(B, L) / (attn_ms * 1e-3) / 1e9
         out = {
             "metric": "denoising-steps/sec (batched pocket graphs)",
@@ -206,6 +237,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "gemm_mode": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                          "bf16x3": "fp32 operands split into 2 bf16 terms, 3 cross products on the bf16 MFMA, fp32 accumulate",
+                          "bf16x6": "fp32 operands split into 3 bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate "
+                                    "(fp32-grade)"}[args.gemm_mode],
+            "value_by_gemm_mode": {m: B * world / by_mode[m] for m in modes},
             "config": {"workload": f"structure_model sampling step, {B} x {L}-residue pockets per GPU, "
                                    "12+12 layers x 768, T=1000 schedule, encoder recomputed every step (as the reference)",
                        "pockets_per_gpu": B, "seq_len": L, "parallelism": f"pocket-sharded x{world}, no collective"},
@@ -216,10 +252,11 @@ def main():
                          "frac": a_tf / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": attn_ms, "launches_per_step": n_attn,
                          "hbm_algorithmic_GBps": a_gb, "hbm_frac": a_gb / PEAK_HBM_GBPS},
-            "roofline_gemm": {"kernel": "gemm_nt_f32 (e3d_gemm_bias_act_f32), all launches of one step",
-                              "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
-                              "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                              "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+            "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",
+                              "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
+                              "peak": gemm_peak, "unit": "TFLOP/s (algorithmic 2MNK)",
+                              "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / gemm_peak,
+                              "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes",
                               "ms_per_step": gemm_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

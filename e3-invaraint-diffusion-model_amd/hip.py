@@ -17,6 +17,7 @@ _SIGNATURES = {
     "e3d_abi_version": (c_int, []),
     "e3d_last_error": (c_char_p, []),
     "e3d_gemm_bias_act_f32": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "e3d_gemm_bias_act_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "e3d_relkey_attn_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                     _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, c_int, _P]),

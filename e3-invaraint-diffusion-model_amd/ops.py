@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C-ABI: allocate outputs with torch (device memory + stream
 plumbing only) and enqueue the HIP kernels on torch's current stream."""
+import os
+
 import torch
 
 from . import hip
@@ -45,7 +47,24 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def gemm(a, weight, bias=None, act=ACT_NONE, out=None):
+# GEMM arithmetic: "f32" = exact fp32 MFMA; "bf16x3" / "bf16x6" = fp32 operands split into 2 / 3
+# bf16 terms on the bf16 matrix cores with fp32 accumulation (gemm_split.hip).  bf16x6 is fp32-grade
+# (4e-7 end-to-end vs 1.8e-6 for fp32 itself), bf16x3 ~2.6e-5 end-to-end (tolerance 1e-4).
+GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6}
+GEMM_MODE = os.environ.get("E3D_GEMM_MODE", "bf16x3")
+if GEMM_MODE not in GEMM_MODES:
+    raise ValueError(f"E3D_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {GEMM_MODE!r}")
+
+
+def set_gemm_mode(mode):
+    global GEMM_MODE
+    if mode not in GEMM_MODES:
+        raise ValueError(f"gemm mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+    prev, GEMM_MODE = GEMM_MODE, mode
+    return prev
+
+
+def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
     """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view."""
     _chk(a, "gemm.a"); _chk(weight, "gemm.weight"); _chk(bias, "gemm.bias")
     assert a.dim() == 2 and a.stride(1) == 1 and weight.is_contiguous()
@@ -55,9 +74,15 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None):
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
+    terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
     with _timed("gemm", (M, N, K)):
-        hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
-                                                  out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
+        if terms == 0:
+            hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
+                                                      out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
+        else:
+            hip.check(hip.lib().e3d_gemm_bias_act_f32_split(
+                _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _stream()),
+                "e3d_gemm_bias_act_f32_split")
     return out
 
 

@@ -41,6 +41,14 @@ const char* e3d_last_error(void);
 int e3d_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const float* bias,
                           float* out, int64_t ldc, int M, int N, int K, int act, void* stream);
 
+/* Same contract as e3d_gemm_bias_act_f32, computed on the bf16 matrix cores with each fp32
+ * operand split into 2 (terms = 3 cross products) or 3 (terms = 6) bf16 terms and fp32
+ * accumulation: fp32-grade results (terms = 6: ~2^-24 per product; terms = 3: ~2^-17) at 6/16 or
+ * 3/16 of the exact kernel's MFMA cost. */
+int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
+                                float* out, int64_t ldc, int M, int N, int K, int act, int terms,
+                                void* stream);
+
 /* Fused attention, head dim 64 ("edge aggregation" of the north star):
  *   S = (Q K^T + R) / sqrt(64) + (1 - key_mask) * -10000;  out = softmax(S) V
  *   R[l,r] = q_l . dist_emb[l - r + P - 1]   (relative_key, only when dist_emb != NULL)

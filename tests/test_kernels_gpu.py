@@ -22,14 +22,26 @@ def g(seed):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 32), (130, 256, 64), (257, 768, 768), (1000, 1024, 3072),
                                    (64, 4608, 768), (4096, 2304, 768)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_gemm_bias_act(pkg, hip, M, N, K, act):
+@pytest.mark.parametrize("mode,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 3e-5)])
+def test_gemm_bias_act(pkg, hip, M, N, K, act, mode, tol):
+    """All three arithmetic modes against an fp64 statement: exact fp32 MFMA, and fp32 operands
+    split into 3 / 2 bf16 terms on the bf16 matrix cores (fp32 accumulate)."""
     a = torch.randn(M, K, generator=g(M + N))
     w = torch.randn(N, K, generator=g(K)) / math.sqrt(K)
     b = torch.randn(N, generator=g(7))
     ref = F.linear(a.double(), w.double(), b.double())
     ref = {0: lambda x: x, 1: F.gelu, 2: F.silu}[act](ref).float()
-    got = pkg.ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), act)
-    assert rel_err(got, ref) < 5e-6
+    got = pkg.ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), act, mode=mode)
+    assert rel_err(got, ref) < tol
+
+
+def test_gemm_split_handles_wide_dynamic_range(pkg, hip):
+    """Split terms must reconstruct operands spanning many binades (outliers next to tiny values)."""
+    a = torch.randn(300, 256, generator=g(1)) * torch.logspace(-6, 4, 256)[None, :]
+    w = torch.randn(128, 256, generator=g(2)) * torch.logspace(3, -5, 256)[None, :]
+    ref = (a.double() @ w.double().t()).float()
+    assert rel_err(pkg.ops.gemm(a.to(DEV), w.to(DEV), None, mode="bf16x6"), ref) < 5e-6
+    assert rel_err(pkg.ops.gemm(a.to(DEV), w.to(DEV), None, mode="bf16x3"), ref) < 3e-5
 
 
 def test_gemm_strided_input_and_no_bias(pkg, hip):

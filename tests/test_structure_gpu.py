@@ -100,6 +100,32 @@ def test_forward_matches_oracle_full_width_with_relkey(pkg, hip, layers, B, L):
         assert rel_err(got, want) < TOL
 
 
+def test_gemm_arithmetic_modes_end_to_end(pkg, hip, capsys):
+    """Full 12+12-layer model, L=128: exact fp32 MFMA vs bf16-split GEMM modes, all against the
+    oracle.  bf16x6 is fp32-grade; bf16x3 (the default) must stay inside the 1e-4 budget with margin."""
+    cfg = dict(FULL_STRUCT, num_hidden_layers=12)
+    B, L = 2, 128
+    model, sd = build(pkg, cfg, L, seed=42)
+    pk = synthetic_pockets(B, L, seed=11)
+    x_t = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=torch.Generator().manual_seed(1)))
+    t = torch.full((B,), 321)
+    want = ostr.forward(sd, {"num_heads": 12, "max_pos": L}, t, x_t, pk["ligand_attn_mask"], pk["receptor_seq"],
+                        pk["receptor_angles"], pk["receptor_attn_mask"])
+    d = to_dev(pk)
+    errs = {}
+    for mode, bound in (("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", TOL / 2)):
+        prev = pkg.ops.set_gemm_mode(mode)
+        try:
+            got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
+                        d["receptor_attn_mask"])
+        finally:
+            pkg.ops.set_gemm_mode(prev)
+        errs[mode] = rel_err(got, want)
+        assert errs[mode] < bound, (mode, errs)
+    with capsys.disabled():
+        print(f"\n[gemm modes, 12+12 layers, L=128] rel err vs oracle: {errs}")
+
+
 def test_cached_receptor_path_is_identical(pkg, hip):
     """encode_receptor once + decode == forward (the sampler's F5 restructuring changes nothing)."""
     cfg = dict(FULL_STRUCT, num_hidden_layers=2)
