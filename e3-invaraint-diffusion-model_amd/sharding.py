@@ -1,0 +1,120 @@
+"""One process per GPU: pocket sharding for sampling, gradient averaging for training.
+
+Pockets are independent (attention never crosses batch items; schedules are small replicated
+tables), so sampling needs NO collective on the data path -- only a gather of the finished
+samples.  Training is data parallel: an all-reduce of the fp32 gradients (RCCL over xGMI via
+torch.distributed backend "nccl"; "gloo" on CPU for the plumbing tests), bucketed so that a
+handful of large messages cross the point-to-point xGMI links instead of ~500 small ones.
+The reference is single-GPU; this file is new work for BASELINE configs 4-5.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world, local_rank); a single process needs no group and gets (0, 1, 0)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local_rank
+
+
+def shard_slice(n_items, rank, world):
+    """Contiguous, balanced [start, stop) of ``n_items`` for ``rank`` (first n % world ranks get
+    one extra item), so concatenating the ranks' outputs in rank order restores dataset order."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_in_rank_order(local_items):
+    """list (picklable, e.g. numpy trajectories trimmed to ligand length) -> the concatenation
+    over ranks on every rank.  One collective at the END of sampling (a few MB)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(local_items)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, list(local_items))
+    return [x for part in parts for x in part]
+
+
+def max_over_ranks(value):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class GradientAverager:
+    """Bucketed all-reduce(sum)/world of parameter gradients.
+
+    The bucket plan is STATIC (built from the parameter list, identical on every rank), and a
+    parameter whose grad is None contributes zeros -- the sequence model owns parameters that its
+    forward never touches (``receptor_feature_emb``, reference sequence_model/model.py:176 vs 221),
+    which would desynchronise a plan built from the non-None grads."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in self.params:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._flat = {}
+
+    def average(self):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        handles = []
+        for i, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = self._flat.get(i)
+            if flat is None or flat.device != bucket[0].device:
+                flat = self._flat[i] = torch.empty(n, dtype=torch.float32, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                dst = flat[off:off + p.numel()]
+                if p.grad is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(p.grad.reshape(-1))
+                off += p.numel()
+            handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
+        for work, flat, bucket in handles:     # buckets overlap each other on the wire
+            work.wait()
+            off = 0
+            for p in bucket:
+                g = flat[off:off + p.numel()].view_as(p) / world
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank ``src``'s weights (DDP construction semantics)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)

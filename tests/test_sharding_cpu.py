@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing -- pocket sharding + final gather (sampling) and
+bucketed gradient averaging incl. never-used parameters (training)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import __graft_entry__
+    pkg = __graft_entry__.load_package()
+    from e3diff_amd import sharding as S
+    r, w, _ = S.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+
+    # ---- sampling: shard 7 pockets, "sample" locally, gather in dataset order
+    lo, hi = S.shard_slice(7, rank, world)
+    local = [f"pocket{i}" for i in range(lo, hi)]
+    gathered = S.gather_in_rank_order(local)
+    assert gathered == [f"pocket{i}" for i in range(7)], gathered
+    assert S.max_over_ranks(1.0 + rank) == float(world)
+
+    # ---- training: averaged grads == mean over ranks; a never-used parameter stays in sync
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"a": torch.nn.Linear(5, 3), "unused": torch.nn.Linear(4, 4),
+                                 "b": torch.nn.Linear(3, 2)})
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    S.broadcast_parameters(model, src=0)
+    x = torch.full((2, 5), float(rank + 1))
+    model["b"](model["a"](x)).sum().backward()
+    local_grad = model["a"].weight.grad.clone()
+    avg = S.GradientAverager(model.parameters(), bucket_bytes=64)   # tiny buckets: several collectives
+    assert len(avg.buckets) > 2
+    avg.average()
+    both = [torch.zeros_like(local_grad) for _ in range(world)]
+    torch.distributed.all_gather(both, local_grad)
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
+    assert model["unused"].weight.grad is not None and float(model["unused"].weight.grad.abs().sum()) == 0.0
+    w0 = [torch.zeros_like(model["a"].weight) for _ in range(world)]
+    torch.distributed.all_gather(w0, model["a"].weight.data)
+    assert torch.equal(w0[0], w0[1])
+    q.put((rank, "ok"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_gradient_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+@pytest.mark.parametrize("n,world", [(7, 2), (1024, 8), (5, 8), (0, 3)])
+def test_shard_slice_partitions(n, world):
+    import __graft_entry__
+    __graft_entry__.load_package()
+    from e3diff_amd.sharding import shard_slice
+    spans = [shard_slice(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = [b - a for a, b in spans]
+    assert max(sizes) - min(sizes) <= 1

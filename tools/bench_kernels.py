@@ -66,6 +66,17 @@ def bench_attn():
                   flush=True)
 
 
+def attn_pmc():
+    """Few launches of the bench.py attention shape (B=256, L=256, rel-key) for a rocprofv3 --pmc pass."""
+    B, L, nh, H = 256, 256, 12, 768
+    qkv = torch.randn(B * L, 3 * H, device=DEV)
+    E = torch.randn(2 * L - 1, 64, device=DEV)
+    mask = torch.ones(B, L, device=DEV)
+    for _ in range(5):
+        ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask, dist_emb=E, max_pos=L)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "attn": bench_attn}[what]()
+    {"gemm": bench_gemm, "attn": bench_attn, "attn_pmc": attn_pmc}[what]()
