@@ -1,0 +1,260 @@
+"""Differentiable versions of the fused ops: torch.autograd.Function shells whose forward AND
+backward are the HIP kernels (the reference trains through torch.autograd on stock ops; here every
+fused forward kernel has a hand-written backward kernel behind the same C-ABI).
+
+``functional.*`` entry points pick the plain inference op when no gradient is required, so the
+sampling path pays nothing for the training support.
+"""
+import torch
+
+from . import hip, ops
+from .ops import _chk, _p, _stream
+
+
+# ----------------------------------------------------------------------------- raw backward wrappers
+def gemm_general(a, a_kmajor, b, b_kmajor, M, N, K, bias=None, act=ops.ACT_NONE, mode=None):
+    """out[M,N] = act(A . B^T + bias) with per-operand storage order (include/e3d_hip.h)."""
+    _chk(a, "gemm_general.a"); _chk(b, "gemm_general.b"); _chk(bias, "gemm_general.bias")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    terms = ops.GEMM_MODES[ops.GEMM_MODE if mode is None else mode] or 6   # exact-f32 mode: fp32-grade split
+    hip.check(hip.lib().e3d_gemm_f32_split_general(_p(a), a.stride(0), int(a_kmajor), _p(b), b.stride(0),
+                                                   int(b_kmajor), _p(bias), _p(out), out.stride(0), M, N, K, act,
+                                                   terms, _stream()), "e3d_gemm_f32_split_general")
+    return out
+
+
+def colsum(x):
+    out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_colsum(_p(x), x.stride(0), _p(out), x.shape[0], x.shape[1], _stream()), "e3d_colsum")
+    return out
+
+
+def group_sum(x, rows_per_group):
+    M, H = x.shape
+    out = torch.empty((M // rows_per_group, H), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_group_sum(_p(x), rows_per_group, _p(out), M, H, _stream()), "e3d_group_sum")
+    return out
+
+
+def act_fwd(z, act):
+    out = torch.empty_like(z)
+    hip.check(hip.lib().e3d_act_fwd(_p(z), act, _p(out), z.numel(), _stream()), "e3d_act_fwd")
+    return out
+
+
+def act_bwd(dh, z, act):
+    dz = torch.empty_like(z)
+    hip.check(hip.lib().e3d_act_bwd(_p(dh), _p(z), act, _p(dz), z.numel(), _stream()), "e3d_act_bwd")
+    return dz
+
+
+def layernorm_bwd(dy, s, gamma, eps, want_affine_grads=True):
+    M, H = s.shape
+    ds = torch.empty_like(s)
+    dg = torch.empty((H,), device=s.device, dtype=torch.float32) if want_affine_grads else None
+    db = torch.empty((H,), device=s.device, dtype=torch.float32) if want_affine_grads else None
+    hip.check(hip.lib().e3d_layernorm_bwd(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dg), _p(db), M, H, _stream()),
+              "e3d_layernorm_bwd")
+    return ds, dg, db
+
+
+def small_k_wgrad(g, x, transpose_out=False, want_bias=True):
+    M, H = g.shape
+    Fk = x.shape[1]
+    dW = torch.empty((Fk, H) if transpose_out else (H, Fk), device=g.device, dtype=torch.float32)
+    db = torch.empty((H,), device=g.device, dtype=torch.float32) if want_bias else None
+    hip.check(hip.lib().e3d_small_k_wgrad(_p(g), _p(x), _p(dW), _p(db), M, H, Fk, int(transpose_out), _stream()),
+              "e3d_small_k_wgrad")
+    return dW, db
+
+
+# ----------------------------------------------------------------------------- autograd Functions
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b); training keeps the pre-activation z (the inference path fuses act into
+    the GEMM epilogue instead)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        z = ops.gemm(x, weight, bias, ops.ACT_NONE)
+        ctx.act = act
+        ctx.save_for_backward(x, weight, z if act != ops.ACT_NONE else None)
+        ctx.has_bias = bias is not None
+        return act_fwd(z, act) if act != ops.ACT_NONE else z
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, z = ctx.saved_tensors
+        dy = dy.contiguous()
+        dz = act_bwd(dy, z, ctx.act) if ctx.act != ops.ACT_NONE else dy
+        M, K = x.shape
+        N = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_general(dz, False, weight, True, M, K, N)          # dz [M,N] . W[N,K]
+        if ctx.needs_input_grad[1]:
+            dw = gemm_general(dz, True, x, True, N, K, M)                # dz^T [N,M] . x [M,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz)
+        return dx, dw, db, None
+
+
+class _Attention(torch.autograd.Function):
+    """Fused attention on PACKED projections so that the gradients come back packed too:
+    self-attention: ``q_src`` = qkv [B*L, 3H], ``kv_src`` = None -> grad dqkv [B*L, 3H];
+    cross-attention: ``q_src`` = q [B*Lq, H], ``kv_src`` = kv [B*Lk, 2H] -> grads dq, dkv."""
+
+    @staticmethod
+    def _views(q_src, kv_src, H):
+        if kv_src is None:
+            return q_src[:, :H], q_src[:, H:2 * H], q_src[:, 2 * H:]
+        return q_src, kv_src[:, :H], kv_src[:, H:]
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos):
+        H = nh * 64
+        q, k, v = _Attention._views(q_src, kv_src, H)
+        out, lse = ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos,
+                                 want_lse=True)
+        ctx.save_for_backward(q_src, kv_src, dist_emb, key_mask, out, lse)
+        ctx.dims = (B, nh, Lq, Lk, max_pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_src, kv_src, dist_emb, key_mask, out, lse = ctx.saved_tensors
+        B, nh, Lq, Lk, max_pos = ctx.dims
+        H = nh * 64
+        dout = dout.contiguous()
+        q, k, v = _Attention._views(q_src, kv_src, H)
+        dq_src = torch.empty_like(q_src)
+        dkv_src = torch.empty_like(kv_src) if kv_src is not None else None
+        dq, dk, dv = _Attention._views(dq_src, dkv_src, H)
+        dE = torch.empty_like(dist_emb) if dist_emb is not None else None
+        lib = hip.lib()
+        ws = torch.empty((lib.e3d_relkey_attn_bwd_workspace_floats(B, nh, Lq, Lk, int(dist_emb is not None)),),
+                         device=q.device, dtype=torch.float32)
+        hip.check(lib.e3d_relkey_attn_bwd(
+            _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0), _p(v), Lk * v.stride(0),
+            v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse), _p(dout),
+            _p(dq), Lq * dq.stride(0), dq.stride(0), _p(dk), Lk * dk.stride(0), dk.stride(0),
+            _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, _stream()),
+            "e3d_relkey_attn_bwd")
+        return dq_src, dkv_src, dE, None, None, None, None, None, None
+
+
+class _ResidualLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps):
+        out, s = ops.residual_layernorm(x, residual, gamma, beta, eps, want_s=True)
+        ctx.save_for_backward(s, gamma)
+        ctx.eps, ctx.has_res = eps, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, gamma = ctx.saved_tensors
+        ds, dg, db = layernorm_bwd(dy.contiguous(), s, gamma, ctx.eps)
+        return ds, (ds if ctx.has_res else None), dg, db, None
+
+
+class _AdaLNGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, mod, branch, rows_per_cond):
+        ctx.save_for_backward(y, mod)
+        ctx.branch, ctx.rpc = branch, rows_per_cond
+        return ops.adaln_gate(x, y, mod, branch, rows_per_cond)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mod = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, H = y.shape
+        dy = torch.empty_like(y)
+        dmod = torch.zeros_like(mod)      # this branch's three chunks; autograd sums the two branches
+        hip.check(hip.lib().e3d_adaln_gate_bwd(_p(dout), _p(y), _p(mod), ctx.branch, ctx.rpc, _p(dy), _p(dmod), M, H,
+                                               _stream()), "e3d_adaln_gate_bwd")
+        return dout, dy, dmod, None, None
+
+
+class _EmbedLayerNorm(torch.autograd.Function):
+    """LN(x W^T + b) * gamma + beta (+ post_add): x is data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, eps, post_add, rows_per_add):
+        out, z = ops.embed_layernorm(x, weight, bias, gamma, beta, eps, post_add, rows_per_add, want_z=True)
+        ctx.save_for_backward(x, z, gamma)
+        ctx.eps, ctx.rpa, ctx.has_add = eps, rows_per_add, post_add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, z, gamma = ctx.saved_tensors
+        dout = dout.contiguous()
+        dz, dg, db_ln = layernorm_bwd(dout, z, gamma, ctx.eps)
+        dW, db = small_k_wgrad(dz, x)
+        dadd = group_sum(dout, ctx.rpa) if (ctx.has_add and ctx.needs_input_grad[6]) else None
+        return None, dW, db, dg, db_ln, None, dadd, None
+
+
+class _HeadLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return ops.head_linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, H = x.shape
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().e3d_head_linear_bwd_dx(_p(dout), _p(weight), _p(dx), M, H, weight.shape[0], _stream()),
+                  "e3d_head_linear_bwd_dx")
+        dW, _ = small_k_wgrad(x, dout, transpose_out=True, want_bias=False)   # [n_out, H]
+        return dx, dW, colsum(dout)
+
+
+# ----------------------------------------------------------------------------- functional front-end
+def _needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+class functional:
+    @staticmethod
+    def linear(x, weight, bias=None, act=ops.ACT_NONE):
+        if _needs_grad(x, weight, bias):
+            return _Linear.apply(x, weight, bias, act)
+        return ops.gemm(x, weight, bias, act)
+
+    @staticmethod
+    def attention(q_src, kv_src, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0):
+        """q_src = packed qkv [B*L,3H] (kv_src None, self-attention) or q [B*Lq,H] with packed kv [B*Lk,2H]."""
+        if _needs_grad(q_src, kv_src, dist_emb):
+            return _Attention.apply(q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos)
+        q, k, v = _Attention._views(q_src, kv_src, nh * 64)
+        return ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos)
+
+    @staticmethod
+    def residual_layernorm(x, residual, gamma, beta, eps):
+        if _needs_grad(x, residual, gamma, beta):
+            return _ResidualLayerNorm.apply(x, residual, gamma, beta, eps)
+        return ops.residual_layernorm(x, residual, gamma, beta, eps)
+
+    @staticmethod
+    def adaln_gate(x, y, mod, branch, rows_per_cond):
+        if _needs_grad(x, y, mod):
+            return _AdaLNGate.apply(x, y, mod, branch, rows_per_cond)
+        return ops.adaln_gate(x, y, mod, branch, rows_per_cond)
+
+    @staticmethod
+    def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_add=1):
+        if _needs_grad(weight, bias, gamma, beta, post_add):
+            return _EmbedLayerNorm.apply(x, weight, bias, gamma, beta, eps, post_add, rows_per_add)
+        return ops.embed_layernorm(x, weight, bias, gamma, beta, eps, post_add, rows_per_add)
+
+    @staticmethod
+    def head_linear(x, weight, bias):
+        if _needs_grad(x, weight, bias):
+            return _HeadLinear.apply(x, weight, bias)
+        return ops.head_linear(x, weight, bias)

@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .autograd import functional as F
 
 
 @dataclass
@@ -115,8 +116,12 @@ class BertEncoder(nn.Module):
 
 # ----------------------------------------------------------------------------- packed weights
 def _packed(owner, name, tensors):
-    """cat() of per-projection weights, cached on the owner and rebuilt when any source
-    parameter changes (in-place update or re-assignment)."""
+    """cat() of per-projection weights.  Inference: cached on the owner and rebuilt when any
+    source parameter changes (in-place update or re-assignment).  Training (a source requires grad
+    and autograd is on): a fresh differentiable torch.cat, so the packed gradient is split back
+    onto query/key/value by autograd."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return torch.cat(list(tensors), dim=0)
     key = tuple((t.data_ptr(), t._version) for t in tensors)
     cache = owner.__dict__.setdefault("_e3d_pack", {})
     hit = cache.get(name)
@@ -137,35 +142,46 @@ def kv_weights(sa):
             _packed(sa, "b_kv", [sa.key.bias, sa.value.bias]))
 
 
+def warn_dropout_once(module, p):
+    """The HIP path has no dropout kernels yet: training runs with dropout disabled (the
+    reference trains with p = 0.1, structure_model/train_model.py:25).  Warn once per module."""
+    if module.training and p and not module.__dict__.get("_e3d_warned"):
+        import warnings
+        warnings.warn(f"dropout p={p} requested in training mode: the HIP kernels apply no dropout "
+                      "(DESIGN.md section 8)", stacklevel=3)
+        module.__dict__["_e3d_warned"] = True
+
+
 # ----------------------------------------------------------------------------- executors
+def _attention_output(att, ctx, x):
+    o = F.linear(ctx, att.output.dense.weight, att.output.dense.bias)
+    return F.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+
+
 def run_self_attention(att, x, mask, B, L):
     """BertAttention on x [B*L,H] with key padding mask [B,L] (1/0): fused QKV GEMM ->
     fused relative-key attention -> out-proj GEMM -> residual + LayerNorm."""
     sa = att.self
-    H = x.shape[1]
     w, b = qkv_weights(sa)
-    qkv = ops.gemm(x, w, b)
+    qkv = F.linear(x, w, b)
     relkey = sa.position_embedding_type == "relative_key"
-    ctx = ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, att.num_heads, L, L, key_mask=mask,
-                        dist_emb=sa.distance_embedding.weight if relkey else None,
-                        max_pos=sa.max_position_embeddings)
-    o = ops.gemm(ctx, att.output.dense.weight, att.output.dense.bias)
-    return ops.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+    ctx = F.attention(qkv, None, B, att.num_heads, L, L, key_mask=mask,
+                      dist_emb=sa.distance_embedding.weight if relkey else None,
+                      max_pos=sa.max_position_embeddings)
+    return _attention_output(att, ctx, x)
 
 
 def project_cross_kv(att, enc):
     """K/V projection of the encoder states for one decoder layer -> [B*Lk, 2H].  It depends on
     neither the timestep nor the noised ligand, so samplers compute it once."""
     w, b = kv_weights(att.self)
-    return ops.gemm(enc, w, b)
+    return F.linear(enc, w, b)
 
 
 def run_cross_attention(att, x, kv, enc_mask, B, Lq, Lk):
-    H = x.shape[1]
-    q = ops.gemm(x, att.self.query.weight, att.self.query.bias)
-    ctx = ops.attention(q, kv[:, :H], kv[:, H:], B, att.num_heads, Lq, Lk, key_mask=enc_mask)
-    o = ops.gemm(ctx, att.output.dense.weight, att.output.dense.bias)
-    return ops.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+    q = F.linear(x, att.self.query.weight, att.self.query.bias)
+    ctx = F.attention(q, kv, B, att.num_heads, Lq, Lk, key_mask=enc_mask)
+    return _attention_output(att, ctx, x)
 
 
 def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None):
@@ -174,14 +190,15 @@ def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None):
         if cross_kv is None:
             raise ValueError("decoder layer needs encoder states")
         x = run_cross_attention(layer.crossattention, x, cross_kv, enc_mask, B, L, Lk)
-    inter = ops.gemm(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
-    o = ops.gemm(inter, layer.output.dense.weight, layer.output.dense.bias)
-    return ops.residual_layernorm(o, x, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps)
+    inter = F.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
+    o = F.linear(inter, layer.output.dense.weight, layer.output.dense.bias)
+    return F.residual_layernorm(o, x, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps)
 
 
 def run_encoder(encoder, x, mask, B, L, enc=None, enc_mask=None, Lk=None, cross_kv=None):
     """BertEncoder(...).last_hidden_state on flat activations.  ``cross_kv`` (list, one per
     layer) short-cuts the per-layer K/V projection of ``enc``."""
+    warn_dropout_once(encoder, getattr(encoder.config, "hidden_dropout_prob", 0.0))
     for i, layer in enumerate(encoder.layer):
         kv = None
         if hasattr(layer, "crossattention"):

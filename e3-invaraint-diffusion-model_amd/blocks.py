@@ -7,6 +7,7 @@ import torch
 from torch import nn
 
 from . import bert, ops
+from .autograd import functional as F
 
 
 class SELayer(nn.Module):
@@ -32,12 +33,12 @@ class SELayer(nn.Module):
         rows_per_cond = x.shape[0] // c.shape[0]
         assert rows_per_cond in (1, L), (x.shape, c.shape)
         m0, m2 = self.adaLN_modulation[0], self.adaLN_modulation[2]
-        mod = ops.gemm(ops.gemm(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
+        mod = F.linear(F.linear(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
         att = bert.run_self_attention(self.attn, x, mask, B, L)
-        x = ops.adaln_gate(x, att, mod, 0, rows_per_cond)
-        h = ops.gemm(x, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_GELU)
-        h = ops.gemm(h, self.mlp[3].weight, self.mlp[3].bias)
-        return ops.adaln_gate(x, h, mod, 1, rows_per_cond)
+        x = F.adaln_gate(x, att, mod, 0, rows_per_cond)
+        h = F.linear(x, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_GELU)
+        h = F.linear(h, self.mlp[3].weight, self.mlp[3].bias)
+        return F.adaln_gate(x, h, mod, 1, rows_per_cond)
 
 
 class GaussianFourierProjection(nn.Module):
@@ -70,7 +71,7 @@ class BertEmbeddings(nn.Module):
         self.dropout = nn.Dropout(bert_config.hidden_dropout_prob)
 
     def run(self, x2d, post_add=None, rows_per_add=1):
-        return ops.embed_layernorm(x2d, self.linear.weight, self.linear.bias, self.LayerNorm.weight,
+        return F.embed_layernorm(x2d, self.linear.weight, self.linear.bias, self.LayerNorm.weight,
                                    self.LayerNorm.bias, self.LayerNorm.eps, post_add, rows_per_add)
 
 
@@ -86,9 +87,9 @@ class Predictor(nn.Module):
         self.dense2 = nn.Linear(d_model, d_out)
 
     def run(self, x):
-        h = ops.gemm(x, self.dense1.weight, self.dense1.bias, ops.ACT_GELU)
-        h = ops.residual_layernorm(h, None, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        return ops.head_linear(h, self.dense2.weight, self.dense2.bias)
+        h = F.linear(x, self.dense1.weight, self.dense1.bias, ops.ACT_GELU)
+        h = F.residual_layernorm(h, None, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return F.head_linear(h, self.dense2.weight, self.dense2.bias)
 
 
 def flat2d(x):

@@ -1,18 +1,23 @@
 // fp32 GEMM through the bf16 matrix cores with SPLIT operands and fp32 accumulation:
-//     out[M,N] = act(A[M,K] @ W[N,K]^T + bias)
+//     out[M,N] = act(A[M,K] . B[N,K]^T + bias)         (A, B given K-contiguous or K-major)
 // Each fp32 operand x is split on the fly into bf16 terms x = x0 + x1 (+ x2) (xi = rne_bf16 of the
 // running residual) and the product is rebuilt from the significant cross terms:
 //     TERMS = 3:  a0*b0 + a0*b1 + a1*b0                         (error ~2^-17 per product)
 //     TERMS = 6:  + a0*b2 + a2*b0 + a1*b1                       (error ~2^-24: fp32 grade)
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so the 3-/6-term products cost
 // 3/16 / 6/16 of the exact fp32 kernel (gemm_f32.hip).  Accumulation stays fp32 in the MFMA.
-// Accuracy through the full 12+12-layer structure model (CPU emulation):
-// 3 terms 2.6e-5, 6 terms 4.3e-7 relative (fp32 torch itself: 1.8e-6); tolerance 1e-4.
 //
 // Workgroup tile 256x128x32, 8 waves as 4(M) x 2(N), each wave 2x2 MFMA tiles of 32x32 (64
-// accumulator registers).  Staging: global_load_dwordx4 (fp32) -> split in registers -> ds_write_b64
+// accumulator registers).  Staging: global loads (fp32) -> split in registers -> ds_write_b64
 // into per-term bf16 images [rows][32 + 8 pad] (80-byte rows: the ds_read_b128 fragment reads
 // of 16 lanes hit 16 distinct 4-bank slots), double buffered for TERMS = 3.
+//
+// Operand layouts (the three GEMMs of a Linear layer share one kernel):
+//     forward   y  = x W^T : A = x  [M,K] K-contiguous,  B = W [N,K] K-contiguous
+//     dgrad     dx = dy W  : A = dy [M,K'] K-contiguous, B = W as [K'][N'] -> "K-major"
+//     wgrad     dW = dy^T x: A = dy as [K'][M'] K-major,  B = x as [K'][N'] K-major
+// A K-major operand is read with one dword per lane (lanes along the contiguous output index, so
+// every k-row is a coalesced 256-byte segment) and transposed for free by the LDS write.
 #include "e3d_common.h"
 
 namespace {
@@ -37,17 +42,66 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&parts)[NS]) {
     }
 }
 
-template <int NS, int ACT>
-__global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A, int64_t lda,
-                                                     const float* __restrict__ W,
-                                                     const float* __restrict__ bias,
-                                                     float* __restrict__ out, int64_t ldc, int M,
-                                                     int N, int K, int tiles_m, int tiles_n) {
+// One operand's staging: NV float4-equivalents (4 consecutive k of one row) per thread.
+template <int ROWS, bool KMAJ>
+struct Stager {
+    static constexpr int NV = ROWS * 8 / 512;  // items per thread (A: 4, B: 2)
+    const float* src[NV];
+    int off[NV];
+    int64_t ld;
+    int kbase[NV];
+
+    __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int row_limit, int tid) {
+        ld = ld_;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + 512 * i;
+            int r, kg;
+            if (KMAJ) { r = f % ROWS; kg = f / ROWS; }   // lanes along rows: coalesced k-rows
+            else { r = f >> 3; kg = f & 7; }             // lanes along k: 128-byte row segments
+            int gr = row0 + r;
+            gr = gr < row_limit ? gr : row_limit - 1;    // clamp: rows past the edge are discarded later
+            src[i] = KMAJ ? base + gr : base + (int64_t)gr * ld + kg * 4;
+            kbase[i] = kg * 4;
+            off[i] = r * ROW_B + kg * 8;
+        }
+    }
+    __device__ __forceinline__ void load(f32x4 (&v)[NV], int k0, int K) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (KMAJ) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + kbase[i] + j;
+                    v[i][j] = k < K ? src[i][(int64_t)k * ld] : 0.f;   // K tail (token counts) zero-filled
+                }
+            } else {
+                v[i] = *reinterpret_cast<const f32x4*>(src[i] + k0);
+            }
+        }
+    }
+    template <int NS>
+    __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bf16x4 p[NS];
+            split4<NS>(v[i], p);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(img + s * part_bytes + off[i]) = p[s];
+        }
+    }
+};
+
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
+__global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ Bm, int64_t ldb,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t ldc, int M,
+                                                         int N, int K, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NBUF = NS == 2 ? 2 : 1;
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
-    constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);
-    // layout per buffer: A part 0..NS-1, then B part 0..NS-1
+    constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
 
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
@@ -57,24 +111,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A
     const int wr = wid >> 1, wc = wid & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // staging map: float4 index f -> row f>>3, chunk f&7 ; A: 4 per thread, B: 2 per thread
-    const float* a_src[4];
-    const float* b_src[2];
-    int a_off[4], b_off[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 512 * i, r = f >> 3, c = f & 7;
-        int ar = row0 + r;
-        ar = ar < M ? ar : M - 1;
-        a_src[i] = A + (int64_t)ar * lda + c * 4;
-        a_off[i] = r * ROW_B + c * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = tid + 512 * i, r = f >> 3, c = f & 7;
-        b_src[i] = W + (int64_t)(col0 + r) * K + c * 4;
-        b_off[i] = r * ROW_B + c * 8;
-    }
+    Stager<BM, A_KMAJ> sa;
+    Stager<BN, B_KMAJ> sb;
+    sa.init(A, lda, row0, M, tid);
+    sb.init(Bm, ldb, col0, N, tid);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -84,44 +124,23 @@ __global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    f32x4 ra[4], rb[2];
-    auto g_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * BK);
-    };
-    auto lds_store = [&](int buf) {
-        unsigned char* base = smem_raw + buf * BUF_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 p[NS];
-            split4<NS>(ra[i], p);
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                *reinterpret_cast<bf16x4*>(base + s * A_BYTES + a_off[i]) = p[s];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x4 p[NS];
-            split4<NS>(rb[i], p);
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-                *reinterpret_cast<bf16x4*>(base + NS * A_BYTES + s * B_BYTES + b_off[i]) = p[s];
-        }
-    };
-
-    g_load(0);
-    lds_store(0);
+    f32x4 ra[Stager<BM, A_KMAJ>::NV], rb[Stager<BN, B_KMAJ>::NV];
+    sa.load(ra, 0, K);
+    sb.load(rb, 0, K);
+    sa.template store<NS>(ra, smem_raw, A_BYTES);
+    sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES);
     __syncthreads();
 
-    const int nk = K / BK;
+    const int nk = (K + BK - 1) / BK;
     const int a_frag = (wr * 64 + l31) * ROW_B + half * 16;
     const int b_frag = (wc * 64 + l31) * ROW_B + half * 16;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) g_load(kt + 1);
+        if (more) {
+            sa.load(ra, (kt + 1) * BK, K);
+            sb.load(rb, (kt + 1) * BK, K);
+        }
         const unsigned char* ab = smem_raw + cur * BUF_BYTES + a_frag;
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES + b_frag;
 #pragma unroll
@@ -152,12 +171,19 @@ __global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A
                 }
         }
         if (NBUF == 2) {
-            if (more) lds_store(cur ^ 1);
+            if (more) {
+                unsigned char* nb = smem_raw + (cur ^ 1) * BUF_BYTES;
+                sa.template store<NS>(ra, nb, A_BYTES);
+                sb.template store<NS>(rb, nb + NS * A_BYTES, B_BYTES);
+            }
             __syncthreads();
             cur ^= 1;
         } else {
             __syncthreads();  // everyone done reading the single buffer
-            if (more) lds_store(0);
+            if (more) {
+                sa.template store<NS>(ra, smem_raw, A_BYTES);
+                sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES);
+            }
             __syncthreads();
         }
     }
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = col0 + wc * 64 + n * 32 + l31;
-        const float bv = bias ? bias[col] : 0.f;
+        const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -174,54 +200,74 @@ __global__ __launch_bounds__(512) void gemm_nt_split(const float* __restrict__ A
                 float v = acc[m][n][r] + bv;
                 if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                 if (ACT == E3D_ACT_SILU) v = silu(v);
-                if (row < M) out[(int64_t)row * ldc + col] = v;
+                if (row < M && col < N) out[(int64_t)row * ldc + col] = v;
             }
         }
     }
 }
 
-template <int NS, int ACT>
-int launch(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-           int K, hipStream_t s) {
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
+int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
+           int M, int N, int K, hipStream_t s) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_split<NS, ACT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_split<NS, ACT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, A, lda, W, bias, out,
-                       ldc, M, N, K, tiles_m, tiles_n);
-    return e3d_launch_status("e3d_gemm_bias_act_f32_split");
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>), dim3(tiles_m * tiles_n), dim3(512), lds, s, A,
+                       lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n);
+    return e3d_launch_status("e3d_gemm_f32_split");
 }
 
 template <int NS>
-int dispatch_act(int act, const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc,
-                 int M, int N, int K, hipStream_t s) {
-    switch (act) {
-        case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE>(A, lda, W, bias, out, ldc, M, N, K, s);
-        case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU>(A, lda, W, bias, out, ldc, M, N, K, s);
-        case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU>(A, lda, W, bias, out, ldc, M, N, K, s);
+int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
+             const float* bias, float* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
+    if (!a_kmaj && !b_kmaj) {
+        switch (act) {
+            case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+            case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+            case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+        }
+        e3d_set_error("gemm_split: unknown activation %d", act);
+        return -1;
     }
-    e3d_set_error("gemm_split: unknown activation %d", act);
-    return -1;
+    if (act != E3D_ACT_NONE) {
+        e3d_set_error("gemm_split: activations are only fused for the forward (K-contiguous) layout");
+        return -1;
+    }
+    if (!a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, false, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    if (a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, true, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return launch<NS, E3D_ACT_NONE, true, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
 }  // namespace
 
+extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kmajor, const float* B,
+                                          int64_t ldb, int b_kmajor, const float* bias, float* out,
+                                          int64_t ldc, int M, int N, int K, int act, int terms,
+                                          void* stream) {
+    E3D_REQUIRE(A && B && out, "gemm_split: null pointer");
+    E3D_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_split: bad shape M=%d N=%d K=%d", M, N, K);
+    E3D_REQUIRE(terms == 3 || terms == 6, "gemm_split: terms must be 3 or 6 (got %d)", terms);
+    E3D_REQUIRE(ldc >= N, "gemm_split: ldc=%lld < N=%d", (long long)ldc, N);
+    if (!a_kmajor) E3D_REQUIRE(lda >= K && lda % 4 == 0 && K % BK == 0 && ((uintptr_t)A % 16) == 0,
+                               "gemm_split: K-contiguous A needs K%%32==0, lda%%4==0, 16B alignment (K=%d lda=%lld)", K, (long long)lda);
+    else E3D_REQUIRE(lda >= M, "gemm_split: K-major A needs lda >= M");
+    if (!b_kmajor) E3D_REQUIRE(ldb >= K && ldb % 4 == 0 && K % BK == 0 && ((uintptr_t)B % 16) == 0,
+                               "gemm_split: K-contiguous B needs K%%32==0, ldb%%4==0, 16B alignment (K=%d ldb=%lld)", K, (long long)ldb);
+    else E3D_REQUIRE(ldb >= N, "gemm_split: K-major B needs ldb >= N");
+    hipStream_t s = (hipStream_t)stream;
+    if (terms == 3) return dispatch<2>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return dispatch<3>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+}
+
 extern "C" int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W,
                                            const float* bias, float* out, int64_t ldc, int M,
                                            int N, int K, int act, int terms, void* stream) {
-    E3D_REQUIRE(A && W && out, "gemm_split: null pointer");
-    E3D_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_split: bad shape M=%d N=%d K=%d", M, N, K);
-    E3D_REQUIRE(N % BN == 0 && K % BK == 0, "gemm_split: need N%%128==0 and K%%32==0 (N=%d K=%d)", N, K);
-    E3D_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0, "gemm_split: bad strides lda=%lld ldc=%lld", (long long)lda,
-                (long long)ldc);
-    E3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "gemm_split: operands must be 16B aligned");
-    E3D_REQUIRE(terms == 3 || terms == 6, "gemm_split: terms must be 3 or 6 (got %d)", terms);
-    hipStream_t s = (hipStream_t)stream;
-    if (terms == 3) return dispatch_act<2>(act, A, lda, W, bias, out, ldc, M, N, K, s);
-    return dispatch_act<3>(act, A, lda, W, bias, out, ldc, M, N, K, s);
+    E3D_REQUIRE(N % BN == 0, "gemm_split: need N%%128==0 (N=%d)", N);
+    return e3d_gemm_f32_split_general(A, lda, 0, W, (int64_t)K, 0, bias, out, ldc, M, N, K, act, terms, stream);
 }

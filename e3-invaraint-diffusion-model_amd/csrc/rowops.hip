@@ -42,7 +42,7 @@ __device__ __forceinline__ void row_normalize(f32x4 (&r)[V], float eps) {
 template <int V>
 __global__ __launch_bounds__(256) void residual_layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ out, int M) {
+    const float* __restrict__ beta, float eps, float* __restrict__ s_out, float* __restrict__ out, int M) {
     constexpr int H = 256 * V;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void residual_layernorm_kernel(
 #pragma unroll
         for (int i = 0; i < V; ++i) r[i] += t[i];
     }
+    if (s_out) row_store<V>(r, s_out + (int64_t)row * H, lane);  // pre-norm sum, kept for the backward
     row_normalize<V>(r, eps);
     f32x4 g[V], b[V];
     row_load<V>(g, gamma, lane);
@@ -90,7 +91,8 @@ template <int V>
 __global__ __launch_bounds__(256) void embed_layernorm_kernel(
     const float* __restrict__ x, int F, const float* __restrict__ W, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-    const float* __restrict__ post_add, int rows_per_add, float* __restrict__ out, int M) {
+    const float* __restrict__ post_add, int rows_per_add, float* __restrict__ z_out,
+    float* __restrict__ out, int M) {
     constexpr int H = 256 * V;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(
                 if (f < F) acc = fmaf(xin[f], w[f], acc);
             r[i][j] += acc;
         }
+    if (z_out) row_store<V>(r, z_out + (int64_t)row * H, lane);  // pre-LayerNorm activations for the backward
     row_normalize<V>(r, eps);
     f32x4 g[V], b[V];
     row_load<V>(g, gamma, lane);
@@ -166,11 +169,11 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
 
 extern "C" int e3d_residual_layernorm_fwd(const float* x, const float* residual,
                                           const float* gamma, const float* beta, float eps,
-                                          float* out, int M, int H, void* stream) {
+                                          float* s_out, float* out, int M, int H, void* stream) {
     E3D_REQUIRE(x && gamma && beta && out && M > 0, "residual_layernorm: bad arguments");
     const dim3 grid((M + 3) / 4), block(256);
     DISPATCH_V(H, hipLaunchKernelGGL(residual_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x,
-                                     residual, gamma, beta, eps, out, M));
+                                     residual, gamma, beta, eps, s_out, out, M));
     return e3d_launch_status("e3d_residual_layernorm_fwd");
 }
 
@@ -187,14 +190,14 @@ extern "C" int e3d_adaln_gate_fwd(const float* x, const float* y, const float* m
 
 extern "C" int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, const float* b,
                                        const float* gamma, const float* beta, float eps,
-                                       const float* post_add, int rows_per_add, float* out, int M,
-                                       int H, void* stream) {
+                                       const float* post_add, int rows_per_add, float* z_out,
+                                       float* out, int M, int H, void* stream) {
     E3D_REQUIRE(x && W && b && gamma && beta && out && M > 0, "embed_layernorm: bad arguments");
     E3D_REQUIRE(F >= 1 && F <= 32, "embed_layernorm: F must be in [1,32] (F=%d)", F);
     E3D_REQUIRE(!post_add || rows_per_add >= 1, "embed_layernorm: rows_per_add=%d", rows_per_add);
     const dim3 grid((M + 3) / 4), block(256);
     DISPATCH_V(H, hipLaunchKernelGGL(embed_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x, F, W, b,
-                                     gamma, beta, eps, post_add, rows_per_add, out, M));
+                                     gamma, beta, eps, post_add, rows_per_add, z_out, out, M));
     return e3d_launch_status("e3d_embed_layernorm_fwd");
 }
 

@@ -1,0 +1,326 @@
+// Backward / training-side HBM-bound kernels: activation fwd+bwd on saved pre-activations,
+// LayerNorm and adaLN-gate backward, bias (column) and broadcast (group) reductions, and the
+// weight gradients of the small-K embedding / small-N head linears.
+// Row kernels follow rowops.hip: one wavefront per row of H = 256*V floats kept in registers.
+#include "e3d_common.h"
+
+namespace {
+
+template <int V>
+__device__ __forceinline__ void row_load(f32x4 (&r)[V], const float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + 4 * (64 * i + lane));
+}
+template <int V>
+__device__ __forceinline__ void row_store(const f32x4 (&r)[V], float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) *reinterpret_cast<f32x4*>(p + 4 * (64 * i + lane)) = r[i];
+}
+template <int V>
+__device__ __forceinline__ void row_atomic_add(const f32x4 (&r)[V], float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(p + 4 * (64 * i + lane) + j, r[i][j]);
+}
+
+// r <- xhat = (r - mean) * rstd ; returns rstd
+template <int V>
+__device__ __forceinline__ float row_normalize(f32x4 (&r)[V], float eps) {
+    constexpr float inv_h = 1.0f / (256 * V);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += (r[i][0] + r[i][1]) + (r[i][2] + r[i][3]);
+    const float mean = wave_sum(s) * inv_h;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[i][j] -= mean;
+            ss += r[i][j] * r[i][j];
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_h + eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] *= rstd;
+    return rstd;
+}
+
+// g <- rstd * (g - mean(g) - xhat * mean(g * xhat))   (LayerNorm input gradient)
+template <int V>
+__device__ __forceinline__ void ln_input_grad(f32x4 (&g)[V], const f32x4 (&xhat)[V], float rstd) {
+    constexpr float inv_h = 1.0f / (256 * V);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1 += g[i][j];
+            s2 += g[i][j] * xhat[i][j];
+        }
+    const float m1 = wave_sum(s1) * inv_h, m2 = wave_sum(s2) * inv_h;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = rstd * (g[i][j] - m1 - xhat[i][j] * m2);
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partials stay in registers and
+// are added once per wave (float atomics: order-dependent in the last bits).
+template <int V>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ s,
+                                                            const float* __restrict__ gamma, float eps,
+                                                            float* __restrict__ ds, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int M) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    f32x4 ga[V], acc_g[V], acc_b[V];
+    if (gamma) row_load<V>(ga, gamma, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { acc_g[i] = 0.f; acc_b[i] = 0.f; }
+    for (int row = wave; row < M; row += n_waves) {
+        f32x4 x[V], g[V];
+        row_load<V>(x, s + (int64_t)row * H, lane);
+        row_load<V>(g, dy + (int64_t)row * H, lane);
+        const float rstd = row_normalize<V>(x, eps);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            acc_g[i] += g[i] * x[i];
+            acc_b[i] += g[i];
+            if (gamma) g[i] *= ga[i];
+        }
+        ln_input_grad<V>(g, x, rstd);
+        row_store<V>(g, ds + (int64_t)row * H, lane);
+    }
+    if (dgamma) row_atomic_add<V>(acc_g, dgamma, lane);
+    if (dbeta) row_atomic_add<V>(acc_b, dbeta, lane);
+}
+
+// ---------------------------------------------------------------- adaLN gate backward
+template <int V>
+__global__ __launch_bounds__(256) void adaln_gate_bwd_kernel(const float* __restrict__ dout,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mod, int branch,
+                                                             int rows_per_cond, float* __restrict__ dy,
+                                                             float* __restrict__ dmod, int M) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 yh[V], go[V], sh[V], sc[V], ga[V];
+    row_load<V>(yh, y + (int64_t)row * H, lane);
+    const float rstd = row_normalize<V>(yh, 1e-5f);
+    row_load<V>(go, dout + (int64_t)row * H, lane);
+    const int64_t moff = (int64_t)(row / rows_per_cond) * 6 * H + (int64_t)branch * 3 * H;
+    row_load<V>(sh, mod + moff, lane);
+    row_load<V>(sc, mod + moff + H, lane);
+    row_load<V>(ga, mod + moff + 2 * H, lane);
+    f32x4 dsh[V], dsc[V], dga[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        dga[i] = go[i] * (yh[i] * (1.0f + sc[i]) + sh[i]);
+        dsh[i] = go[i] * ga[i];
+        dsc[i] = dsh[i] * yh[i];
+        go[i] = dsh[i] * (1.0f + sc[i]);  // d(yhat)
+    }
+    ln_input_grad<V>(go, yh, rstd);
+    row_store<V>(go, dy + (int64_t)row * H, lane);
+    if (rows_per_cond == 1) {
+        row_store<V>(dsh, dmod + moff, lane);
+        row_store<V>(dsc, dmod + moff + H, lane);
+        row_store<V>(dga, dmod + moff + 2 * H, lane);
+    } else {
+        row_atomic_add<V>(dsh, dmod + moff, lane);
+        row_atomic_add<V>(dsc, dmod + moff + H, lane);
+        row_atomic_add<V>(dga, dmod + moff + 2 * H, lane);
+    }
+}
+
+// ---------------------------------------------------------------- activations on saved z
+__device__ __forceinline__ float act_apply(float z, int act) {
+    return act == E3D_ACT_GELU ? gelu_erf(z) : (act == E3D_ACT_SILU ? silu(z) : z);
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == E3D_ACT_GELU)  // 0.5(1+erf(z/sqrt2)) + z exp(-z^2/2)/sqrt(2 pi)
+        return 0.5f * (1.0f + erff(z * 0.70710678118654752440f)) + z * expf(-0.5f * z * z) * 0.39894228040143267794f;
+    if (act == E3D_ACT_SILU) {
+        const float sg = 1.0f / (1.0f + expf(-z));
+        return sg * (1.0f + z * (1.0f - sg));
+    }
+    return 1.0f;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, int act, float* __restrict__ out,
+                                                      int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = act_apply(z[i], act);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ z, int act,
+                                                      float* __restrict__ dz, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dz[i] = dh[i] * act_grad(z[i], act);
+}
+
+// ---------------------------------------------------------------- reductions
+// out[n] += sum over this block's row span of x[m, n]   (out pre-zeroed by the launcher)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, float* __restrict__ out,
+                                                     int M, int N, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float acc = 0.f;
+    for (int m = m0; m < m1; ++m) acc += x[(int64_t)m * ld + n];
+    atomicAdd(out + n, acc);
+}
+
+// out[g, h] = sum_{i < rows_per_group} x[g * rows_per_group + i, h]   (deterministic)
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ x, int rows_per_group,
+                                                        float* __restrict__ out, int H) {
+    const int h = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y;
+    if (h >= H) return;
+    const float* p = x + (int64_t)grp * rows_per_group * H + h;
+    float acc = 0.f;
+    for (int i = 0; i < rows_per_group; ++i) acc += p[(int64_t)i * H];
+    out[(int64_t)grp * H + h] = acc;
+}
+
+// dW[h, f] (or [f, h]) += sum_m g[m, h] * x[m, f],  db[h] += sum_m g[m, h];  F <= 32.
+__global__ __launch_bounds__(256) void small_k_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            float* __restrict__ dW, float* __restrict__ db, int M,
+                                                            int H, int F, int transpose_out, int rows_per_block) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    if (h >= H) return;
+    float acc[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) acc[f] = 0.f;
+    float accb = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        const float gv = g[(int64_t)m * H + h];
+        const float* xr = x + (int64_t)m * F;
+        accb += gv;
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+            if (f < F) acc[f] = fmaf(gv, xr[f], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < 32; ++f)
+        if (f < F) atomicAdd(dW + (transpose_out ? (int64_t)f * H + h : (int64_t)h * F + f), acc[f]);
+    if (db) atomicAdd(db + h, accb);
+}
+
+// dx[m, :] = sum_n dout[m, n] * W[n, :]   (output head, n <= 32)
+template <int V>
+__global__ __launch_bounds__(256) void head_linear_bwd_dx_kernel(const float* __restrict__ dout,
+                                                                 const float* __restrict__ W, float* __restrict__ dx,
+                                                                 int M, int Nout) {
+    constexpr int H = 256 * V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    f32x4 r[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = 0.f;
+    for (int n = 0; n < Nout; ++n) {
+        const float d = dout[(int64_t)row * Nout + n];
+        f32x4 w[V];
+        row_load<V>(w, W + (int64_t)n * H, lane);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] += d * w[i];
+    }
+    row_store<V>(r, dx + (int64_t)row * H, lane);
+}
+
+#define DISPATCH_V(H, CALL)                                             \
+    switch (H) {                                                        \
+        case 256: { constexpr int V = 1; CALL; } break;                 \
+        case 512: { constexpr int V = 2; CALL; } break;                 \
+        case 768: { constexpr int V = 3; CALL; } break;                 \
+        case 1024: { constexpr int V = 4; CALL; } break;                \
+        default: E3D_REQUIRE(false, "row op: H must be 256/512/768/1024 (H=%d)", H); \
+    }
+
+int elementwise_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* gamma, float eps, float* ds,
+                                 float* dgamma, float* dbeta, int M, int H, void* stream) {
+    E3D_REQUIRE(dy && s && ds && M > 0, "layernorm_bwd: bad arguments");
+    hipError_t e = hipSuccess;
+    if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+    if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+    E3D_REQUIRE(e == hipSuccess, "layernorm_bwd: memset failed: %s", hipGetErrorString(e));
+    const int blocks = (M + 3) / 4 < 256 ? (M + 3) / 4 : 256;
+    DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s,
+                                     gamma, eps, ds, dgamma, dbeta, M));
+    return e3d_launch_status("e3d_layernorm_bwd");
+}
+
+extern "C" int e3d_adaln_gate_bwd(const float* dout, const float* y, const float* mod, int branch,
+                                  int rows_per_cond, float* dy, float* dmod, int M, int H, void* stream) {
+    E3D_REQUIRE(dout && y && mod && dy && dmod && M > 0, "adaln_gate_bwd: bad arguments");
+    E3D_REQUIRE((branch == 0 || branch == 1) && rows_per_cond >= 1, "adaln_gate_bwd: branch=%d rows_per_cond=%d", branch,
+                rows_per_cond);
+    DISPATCH_V(H, hipLaunchKernelGGL(adaln_gate_bwd_kernel<V>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout,
+                                     y, mod, branch, rows_per_cond, dy, dmod, M));
+    return e3d_launch_status("e3d_adaln_gate_bwd");
+}
+
+extern "C" int e3d_act_fwd(const float* z, int act, float* out, int64_t n, void* stream) {
+    E3D_REQUIRE(z && out && n > 0 && act >= 0 && act <= 2, "act_fwd: bad arguments");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(elementwise_blocks(n)), dim3(256), 0, (hipStream_t)stream, z, act, out, n);
+    return e3d_launch_status("e3d_act_fwd");
+}
+
+extern "C" int e3d_act_bwd(const float* dh, const float* z, int act, float* dz, int64_t n, void* stream) {
+    E3D_REQUIRE(dh && z && dz && n > 0 && act >= 0 && act <= 2, "act_bwd: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(elementwise_blocks(n)), dim3(256), 0, (hipStream_t)stream, dh, z, act, dz, n);
+    return e3d_launch_status("e3d_act_bwd");
+}
+
+extern "C" int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, void* stream) {
+    E3D_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    E3D_REQUIRE(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
+    const int rpb = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, x, ld, out, M, N, rpb);
+    return e3d_launch_status("e3d_colsum");
+}
+
+extern "C" int e3d_group_sum(const float* x, int rows_per_group, float* out, int M, int H, void* stream) {
+    E3D_REQUIRE(x && out && M > 0 && H > 0 && rows_per_group >= 1 && M % rows_per_group == 0,
+                "group_sum: bad arguments (M=%d rows_per_group=%d)", M, rows_per_group);
+    hipLaunchKernelGGL(group_sum_kernel, dim3((H + 255) / 256, M / rows_per_group), dim3(256), 0, (hipStream_t)stream, x,
+                       rows_per_group, out, H);
+    return e3d_launch_status("e3d_group_sum");
+}
+
+extern "C" int e3d_small_k_wgrad(const float* g, const float* x, float* dW, float* db, int M, int H, int F,
+                                 int transpose_out, void* stream) {
+    E3D_REQUIRE(g && x && dW && M > 0 && H > 0 && F >= 1 && F <= 32, "small_k_wgrad: bad arguments (F=%d)", F);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dW, 0, (size_t)H * F * sizeof(float), s);
+    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)H * sizeof(float), s);
+    E3D_REQUIRE(e == hipSuccess, "small_k_wgrad: memset failed: %s", hipGetErrorString(e));
+    const int rpb = 64;
+    hipLaunchKernelGGL(small_k_wgrad_kernel, dim3((H + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, g, x, dW, db, M,
+                       H, F, transpose_out, rpb);
+    return e3d_launch_status("e3d_small_k_wgrad");
+}
+
+extern "C" int e3d_head_linear_bwd_dx(const float* dout, const float* W, float* dx, int M, int H, int Nout,
+                                      void* stream) {
+    E3D_REQUIRE(dout && W && dx && M > 0 && Nout >= 1 && Nout <= 32, "head_linear_bwd_dx: bad arguments");
+    DISPATCH_V(H, hipLaunchKernelGGL(head_linear_bwd_dx_kernel<V>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                                     dout, W, dx, M, Nout));
+    return e3d_launch_status("e3d_head_linear_bwd_dx");
+}

@@ -20,9 +20,24 @@ _SIGNATURES = {
     "e3d_gemm_bias_act_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
     "e3d_relkey_attn_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                     _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, c_int, _P]),
+    "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "e3d_adaln_gate_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
-    "e3d_embed_layernorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int, c_int, _P]),
+    "e3d_embed_layernorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, _P, c_int, _P, _P, c_int, c_int, _P]),
+    # training (backward) side
+    "e3d_gemm_f32_split_general": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, c_int64, c_int, c_int,
+                                           c_int, c_int, c_int, _P]),
+    "e3d_relkey_attn_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "e3d_relkey_attn_bwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
+                                    _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                    _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "e3d_layernorm_bwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
+    "e3d_adaln_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P]),
+    "e3d_act_fwd": (c_int, [_P, c_int, _P, c_int64, _P]),
+    "e3d_act_bwd": (c_int, [_P, _P, c_int, _P, c_int64, _P]),
+    "e3d_colsum": (c_int, [_P, c_int64, _P, c_int, c_int, _P]),
+    "e3d_group_sum": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
+    "e3d_small_k_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "e3d_head_linear_bwd_dx": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "e3d_head_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "e3d_ddpm_step_wrap": (c_int, [_P, _P, _P, c_float, c_float, c_float, c_float, c_int, _P, c_int64, _P]),
     "e3d_q_sample_wrap": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, _P]),

@@ -107,15 +107,16 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
     return (out, lse) if want_lse else out
 
 
-def residual_layernorm(x, residual, gamma, beta, eps):
+def residual_layernorm(x, residual, gamma, beta, eps, want_s=False):
     for n, t in (("x", x), ("residual", residual), ("gamma", gamma), ("beta", beta)):
         _chk(t, "residual_layernorm." + n)
     assert x.is_contiguous() and (residual is None or residual.is_contiguous())
     M, H = x.shape
     out = torch.empty_like(x)
-    hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps,
+    s = torch.empty_like(x) if want_s else None
+    hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s),
                                                    _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
-    return out
+    return (out, s) if want_s else out
 
 
 def adaln_gate(x, y, mod, branch, rows_per_cond):
@@ -130,7 +131,7 @@ def adaln_gate(x, y, mod, branch, rows_per_cond):
     return out
 
 
-def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_add=1):
+def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_add=1, want_z=False):
     for n, t in (("x", x), ("weight", weight), ("bias", bias), ("gamma", gamma), ("beta", beta),
                  ("post_add", post_add)):
         _chk(t, "embed_layernorm." + n)
@@ -141,10 +142,11 @@ def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_a
     if post_add is not None:
         assert post_add.is_contiguous() and post_add.shape == (M // rows_per_add, H)
     out = torch.empty((M, H), device=x.device, dtype=torch.float32)
+    z = torch.empty_like(out) if want_z else None
     hip.check(hip.lib().e3d_embed_layernorm_fwd(_p(x), F, _p(weight), _p(bias), _p(gamma), _p(beta), eps,
-                                                _p(post_add), rows_per_add, _p(out), M, H, _stream()),
+                                                _p(post_add), rows_per_add, _p(z), _p(out), M, H, _stream()),
               "e3d_embed_layernorm_fwd")
-    return out
+    return (out, z) if want_z else out
 
 
 def head_linear(x, weight, bias):

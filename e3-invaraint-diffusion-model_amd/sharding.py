@@ -60,6 +60,17 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def mean_over_ranks(value):
+    """Mean of a scalar over ranks (the reference's only collective: ``self.all_gather(val).mean()``
+    on the per-feature validation losses, structure_model/model.py:344)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()
+
+
 class GradientAverager:
     """Bucketed all-reduce(sum)/world of parameter gradients.
 

@@ -1,0 +1,100 @@
+"""Plain training loop that stands in for ``pl.Trainer.fit`` as the reference configures it
+(structure_model/train_model.py:99-116): gradient-norm clipping, AdamW from
+``model.configure_optimizers()``, scheduler stepped per EPOCH (or per step for OneCycleLR),
+validation every epoch, best-checkpoint bookkeeping with the reference's ``mode='max'`` quirk,
+and -- new relative to the single-GPU reference -- data-parallel gradient averaging over RCCL when
+launched with one process per GPU (``torchrun``).
+"""
+import math
+import time
+
+import torch
+
+from . import sharding
+
+
+def move_batch(batch, device):
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+class BestCheckpoint:
+    """ModelCheckpoint(monitor='val_loss', save_top_k=1, mode=...) semantics; the reference passes
+    mode='max', i.e. it keeps the HIGHEST validation loss -- reproduced by default."""
+
+    def __init__(self, path, mode="max"):
+        self.path, self.mode, self.best = path, mode, None
+
+    def update(self, model, val_loss, rank=0):
+        better = self.best is None or (val_loss > self.best if self.mode == "max" else val_loss < self.best)
+        if better:
+            self.best = val_loss
+            if rank == 0 and self.path:
+                torch.save(model.state_dict(), self.path)
+        return better
+
+
+def fit(model, train_loader, val_loader=None, *, max_epochs, min_epochs=0, gradient_clip=1.0, device="cuda:0",
+        log_every_n_steps=30, checkpoint_path="./best_val_model.pt", checkpoint_mode="max", max_steps=None,
+        log=print):
+    """Returns a history dict.  ``model`` provides training_step / validation_step /
+    configure_optimizers (the reference's LightningModule surface)."""
+    rank, world, _ = sharding.init_distributed()
+    model.to(device)
+    sharding.broadcast_parameters(model, src=0)
+    conf = model.configure_optimizers()
+    optim = conf["optimizer"]
+    sched = conf.get("lr_scheduler")
+    averager = sharding.GradientAverager(model.parameters())
+    ckpt = BestCheckpoint(checkpoint_path, checkpoint_mode)
+    history = {"train_loss": [], "val_loss": [], "steps": 0, "seconds": 0.0}
+    params = [p for p in model.parameters() if p.requires_grad]
+    t0 = time.perf_counter()
+    step = 0
+    for epoch in range(max_epochs):
+        model.train()
+        if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        losses = []
+        for batch_idx, batch in enumerate(train_loader):
+            batch = move_batch(batch, device)
+            loss = model.training_step(batch, batch_idx)
+            optim.zero_grad(set_to_none=True)
+            loss.backward()
+            averager.average()                       # RCCL all-reduce (no-op for one process)
+            if gradient_clip:
+                torch.nn.utils.clip_grad_norm_(params, gradient_clip)   # global norm of the averaged grads
+            optim.step()
+            if sched is not None and sched.get("interval") == "step":
+                sched["scheduler"].step()
+            losses.append(float(loss.detach()))
+            step += 1
+            if rank == 0 and log_every_n_steps and step % log_every_n_steps == 0:
+                log(f"epoch {epoch} step {step} train_loss {losses[-1]:.5f}")
+            if max_steps is not None and step >= max_steps:
+                break
+        if sched is not None and sched.get("interval") == "epoch":
+            sched["scheduler"].step()
+        mean_train = sum(losses) / max(1, len(losses))
+        history["train_loss"].append(mean_train)
+        if rank == 0:
+            log(f"Traning Loss:{mean_train}")
+        if val_loader is not None:
+            model.eval()
+            vals = []
+            with torch.no_grad():
+                for batch_idx, batch in enumerate(val_loader):
+                    out = model.validation_step(move_batch(batch, device), batch_idx)
+                    vals.append(float(out["val_loss"] if isinstance(out, dict) else out))
+            val = sum(vals) / max(1, len(vals)) if vals else math.nan
+            if world > 1:
+                val = sharding.mean_over_ranks(val)
+            history["val_loss"].append(val)
+            if rank == 0:
+                log(f"Validation Loss:{val}")
+            if not math.isnan(val):
+                ckpt.update(model, val, rank)
+        if max_steps is not None and step >= max_steps:
+            break
+    history["steps"] = step
+    history["seconds"] = time.perf_counter() - t0
+    return history

@@ -68,10 +68,11 @@ int e3d_relkey_attn_fwd(const float* q, int64_t q_bs, int64_t q_rs,
 /* out[M,H] = LayerNorm_eps(x[M,H] (+ residual[M,H])) * gamma + beta
  * -- BertSelfOutput / BertOutput (4.38.2) with the dense bias already added by the GEMM,
  * and predictor.layer_norm (structure_model/model.py:152).  residual may be NULL.
+ * s_out (may be NULL) receives the pre-norm rows x + residual that the backward needs.
  * H must be 256, 512, 768 or 1024. */
 int e3d_residual_layernorm_fwd(const float* x, const float* residual, const float* gamma,
-                               const float* beta, float eps, float* out, int M, int H,
-                               void* stream);
+                               const float* beta, float eps, float* s_out, float* out, int M,
+                               int H, void* stream);
 
 /* SELayer gated branch (structure_model/model.py:61-67):
  *   out = x + gate * (LayerNorm_1e-5_noaffine(y) * (1 + scale) + shift)
@@ -84,11 +85,12 @@ int e3d_adaln_gate_fwd(const float* x, const float* y, const float* mod, int bra
 /* BertEmbeddings (structure_model/model.py:111-118, eval):
  *   out[M,H] = LayerNorm_eps(x[M,F] @ W[H,F]^T + b) * gamma + beta (+ post_add[m / rows_per_add])
  * post_add ([M / rows_per_add, H], may be NULL) is the timestep embedding the sequence model
- * adds after the embedding (sequence_model/model.py:213,220).  F <= 32. */
+ * adds after the embedding (sequence_model/model.py:213,220).  F <= 32.  z_out (may be NULL)
+ * receives the pre-LayerNorm rows x W^T + b that the backward needs. */
 int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, const float* b,
                             const float* gamma, const float* beta, float eps,
-                            const float* post_add, int rows_per_add, float* out, int M, int H,
-                            void* stream);
+                            const float* post_add, int rows_per_add, float* z_out, float* out,
+                            int M, int H, void* stream);
 
 /* predictor.dense2 (structure_model/model.py:153): out[M,Nout] = x[M,H] @ W[Nout,H]^T + b,
  * Nout <= 32 (8 angles / 20 amino-acid logits). */
@@ -124,6 +126,61 @@ int e3d_discrete_posterior_sample(const int32_t* xt_idx, const float* logits, co
  * x0 index < 0 marks a padding (all-zero one-hot) row -> class 0.  u as above. */
 int e3d_discrete_q_sample(const int32_t* x0_idx, const float* Qtb, const float* u, int mode,
                           int32_t* out_idx, int B, int L, int C, void* stream);
+
+/* ------------------------------------------------------------------ training (backward) side
+ * The reference trains through torch.autograd on these same modules (Lightning training_step,
+ * structure_model/model.py:305-319, sequence_model/model.py:347-367); the entry points below are
+ * the hand-written backward of each fused forward kernel. */
+
+/* General-layout split GEMM (the three GEMMs of one nn.Linear share it):
+ *   out[M,N] = act(A . B^T + bias), A logical [M,K], B logical [N,K];
+ *   x_kmajor = 0: element (r,k) at X[r*ld + k];  x_kmajor = 1: at X[k*ld + r] (transposed storage).
+ *   forward  y = x W^T : (0,0);  dgrad dx = dy W : A = dy (0), B = W as [K'][N'] (1);
+ *   wgrad dW = dy^T x : A = dy (1), B = x (1).  K-major operands allow any K (tail zero-filled). */
+int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb,
+                               int b_kmajor, const float* bias, float* out, int64_t ldc, int M, int N,
+                               int K, int act, int terms, void* stream);
+
+/* Backward of e3d_relkey_attn_fwd.  out / lse are the forward's outputs, dout [B,Lq,nh*64].
+ * Writes dq, dk, dv (strided like q, k, v) and, with dist_emb, d_dist_emb [2P-1,64] (overwritten).
+ * workspace: e3d_relkey_attn_bwd_workspace_floats(...) floats (materialised P and dS tiles + the
+ * per-wave dist_emb partial blocks). */
+int64_t e3d_relkey_attn_bwd_workspace_floats(int B, int nh, int Lq, int Lk, int relkey);
+int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                        int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                        const float* dist_emb, int P, const float* key_mask, const float* out,
+                        const float* lse, const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs,
+                        float* dk, int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs,
+                        int64_t dv_rs, float* d_dist_emb, float* workspace, int B, int nh, int Lq,
+                        int Lk, void* stream);
+
+/* LayerNorm backward on the saved pre-norm rows s [M,H]: ds = dLN/ds, dgamma/dbeta (overwritten;
+ * gamma == NULL: no affine, as SELayer.norm1/norm2). */
+int e3d_layernorm_bwd(const float* dy, const float* s, const float* gamma, float eps, float* ds,
+                      float* dgamma, float* dbeta, int M, int H, void* stream);
+
+/* Backward of e3d_adaln_gate_fwd w.r.t. y (-> dy) and mod (-> dmod [Mc,6H]: stored when
+ * rows_per_cond == 1, ACCUMULATED when > 1 -- zero it once before the two branch calls);
+ * the gradient w.r.t. x is dout itself. */
+int e3d_adaln_gate_bwd(const float* dout, const float* y, const float* mod, int branch,
+                       int rows_per_cond, float* dy, float* dmod, int M, int H, void* stream);
+
+/* Activations on saved pre-activations (training keeps z; inference fuses them into the GEMM). */
+int e3d_act_fwd(const float* z, int act, float* out, int64_t n, void* stream);
+int e3d_act_bwd(const float* dh, const float* z, int act, float* dz, int64_t n, void* stream);
+
+/* out[n] = sum_m x[m,n] (bias gradients);  out[g,:] = sum of rows_per_group consecutive rows. */
+int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, void* stream);
+int e3d_group_sum(const float* x, int rows_per_group, float* out, int M, int H, void* stream);
+
+/* dW[h,f] (transpose_out: [f,h]) = sum_m g[m,h] x[m,f], db[h] = sum_m g[m,h]; F <= 32
+ * (BertEmbeddings.linear and predictor.dense2 weight gradients). */
+int e3d_small_k_wgrad(const float* g, const float* x, float* dW, float* db, int M, int H, int F,
+                      int transpose_out, void* stream);
+
+/* dx[M,H] = dout[M,Nout] @ W[Nout,H] (input gradient of predictor.dense2). */
+int e3d_head_linear_bwd_dx(const float* dout, const float* W, float* dx, int M, int H, int Nout,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,268 @@
+"""GPU: hand-written backward kernels (through the C-ABI and the autograd shells) against CPU
+torch.autograd of the oracle / of plain fp64 statements.  Gradients: 1e-4 relative (max-norm) in
+the fp32-grade GEMM mode, looser where the default bf16x3 GEMM enters (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from helpers import FULL_SEQ, FULL_STRUCT, rel_err, seeded_state_dict, synthetic_pockets
+from oracle import bert as obert, sequence as oseq, structure as ostr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def leaf(t, dev=None, dtype=None):
+    t = t.detach().clone()
+    if dtype is not None:
+        t = t.to(dtype)
+    if dev is not None:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+@pytest.fixture()
+def Fm(pkg):
+    from e3diff_amd.autograd import functional
+    return functional
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-5), ("bf16x3", 1e-4), ("f32", 1e-5)])
+@pytest.mark.parametrize("M,N,K,act", [(96, 256, 128, 0), (300, 768, 1024, 1), (64, 1536, 256, 2), (4096, 768, 768, 0)])
+def test_linear_backward(pkg, hip, Fm, M, N, K, act, mode, tol):
+    x, w, b = torch.randn(M, K, generator=g(1)), torch.randn(N, K, generator=g(2)) / math.sqrt(K), torch.randn(N, generator=g(3))
+    go = torch.randn(M, N, generator=g(4))
+    xr, wr, br = leaf(x, dtype=torch.double), leaf(w, dtype=torch.double), leaf(b, dtype=torch.double)
+    y = TF.linear(xr, wr, br)
+    y = {0: lambda t: t, 1: TF.gelu, 2: TF.silu}[act](y)
+    y.backward(go.double())
+    prev = pkg.ops.set_gemm_mode(mode)
+    try:
+        xd, wd, bd = leaf(x, DEV), leaf(w, DEV), leaf(b, DEV)
+        out = Fm.linear(xd, wd, bd, act)
+        out.backward(go.to(DEV))
+    finally:
+        pkg.ops.set_gemm_mode(prev)
+    assert rel_err(out, y.float()) < tol
+    assert rel_err(xd.grad, xr.grad.float()) < tol
+    assert rel_err(wd.grad, wr.grad.float()) < tol
+    assert rel_err(bd.grad, br.grad.float()) < 1e-5
+
+
+def test_gemm_general_odd_reduction_and_strided(pkg, hip):
+    from e3diff_amd.autograd import gemm_general
+    M, N, K = 70, 200, 45          # K-major operands: any K, any N
+    a, b = torch.randn(K, M, generator=g(1)), torch.randn(K, 300, generator=g(2))
+    got = gemm_general(a.to(DEV), True, b.to(DEV)[:, 50:250], True, M, N, K, mode="bf16x6")
+    assert rel_err(got, (a.t().double() @ b[:, 50:250].double()).float()) < 1e-5
+
+
+@pytest.mark.parametrize("H,M", [(768, 70), (256, 9), (1024, 33)])
+def test_layernorm_and_adaln_backward(pkg, hip, Fm, H, M):
+    x, r = torch.randn(M, H, generator=g(1)) * 2, torch.randn(M, H, generator=g(2))
+    ga, be = 1 + 0.1 * torch.randn(H, generator=g(3)), torch.randn(H, generator=g(4))
+    go = torch.randn(M, H, generator=g(5))
+    xr, rr, gr, br = (leaf(t, dtype=torch.double) for t in (x, r, ga, be))
+    TF.layer_norm(xr + rr, (H,), gr, br, 1e-12).backward(go.double())
+    xd, rd, gd, bd = (leaf(t, DEV) for t in (x, r, ga, be))
+    Fm.residual_layernorm(xd, rd, gd, bd, 1e-12).backward(go.to(DEV))
+    for a, b in ((xd, xr), (rd, rr), (gd, gr), (bd, br)):
+        assert rel_err(a.grad, b.grad.float()) < 1e-5
+    # no residual
+    xd2, gd2, bd2 = leaf(x, DEV), leaf(ga, DEV), leaf(be, DEV)
+    Fm.residual_layernorm(xd2, None, gd2, bd2, 1e-12).backward(go.to(DEV))
+    xr2 = leaf(x, dtype=torch.double)
+    TF.layer_norm(xr2, (H,), ga.double(), be.double(), 1e-12).backward(go.double())
+    assert rel_err(xd2.grad, xr2.grad.float()) < 1e-5
+    # adaLN gate, both broadcast modes and both branches
+    for rpc in (1, M):
+        for branch in (0, 1):
+            y = torch.randn(M, H, generator=g(6)) * 2
+            mod = torch.randn(M // rpc, 6 * H, generator=g(7))
+            xr3, yr3, mr3 = (leaf(t, dtype=torch.double) for t in (x, y, mod))
+            sh, sc, gt = [mr3[:, (3 * branch + i) * H:(3 * branch + i + 1) * H].repeat_interleave(rpc, 0) for i in range(3)]
+            (xr3 + gt * (TF.layer_norm(yr3, (H,)) * (1 + sc) + sh)).backward(go.double())
+            xd3, yd3, md3 = (leaf(t, DEV) for t in (x, y, mod))
+            Fm.adaln_gate(xd3, yd3, md3, branch, rpc).backward(go.to(DEV))
+            for a, b in ((xd3, xr3), (yd3, yr3), (md3, mr3)):
+                assert rel_err(a.grad, b.grad.float()) < 1e-5, (rpc, branch)
+
+
+def test_embed_and_head_backward(pkg, hip, Fm):
+    M, L, H = 48, 16, 768
+    for Fin in (8, 20):
+        x = torch.randn(M, Fin, generator=g(1))
+        w, b = torch.randn(H, Fin, generator=g(2)), torch.randn(H, generator=g(3))
+        ga, be = 1 + 0.1 * torch.randn(H, generator=g(4)), torch.randn(H, generator=g(5))
+        add = torch.randn(M // L, H, generator=g(6))
+        go = torch.randn(M, H, generator=g(7))
+        ref = [leaf(t, dtype=torch.double) for t in (w, b, ga, be, add)]
+        (TF.layer_norm(TF.linear(x.double(), ref[0], ref[1]), (H,), ref[2], ref[3], 1e-12)
+         + ref[4].repeat_interleave(L, 0)).backward(go.double())
+        dev = [leaf(t, DEV) for t in (w, b, ga, be, add)]
+        Fm.embed_layernorm(x.to(DEV), dev[0], dev[1], dev[2], dev[3], 1e-12, dev[4], L).backward(go.to(DEV))
+        for a, r in zip(dev, ref):
+            assert rel_err(a.grad, r.grad.float()) < 1e-5
+    for n_out in (8, 20):
+        x, w, b = torch.randn(77, H, generator=g(1)), torch.randn(n_out, H, generator=g(2)) / 27, torch.randn(n_out, generator=g(3))
+        go = torch.randn(77, n_out, generator=g(4))
+        ref = [leaf(t, dtype=torch.double) for t in (x, w, b)]
+        TF.linear(*ref).backward(go.double())
+        dev = [leaf(t, DEV) for t in (x, w, b)]
+        Fm.head_linear(*dev).backward(go.to(DEV))
+        for a, r in zip(dev, ref):
+            assert rel_err(a.grad, r.grad.float()) < 1e-5
+
+
+def ref_attention(q, k, v, mask, E, P):
+    s = q @ k.transpose(-1, -2)
+    if E is not None:
+        s = s + obert.relkey_scores_literal(q, E, P)
+    s = s / 8.0
+    if mask is not None:
+        s = s + ((1.0 - mask) * -10000.0)[:, None, None, :]
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("B,nh,L,P", [(2, 2, 16, 16), (1, 3, 64, 64), (2, 2, 50, 64), (1, 2, 128, 128), (1, 1, 256, 256)])
+@pytest.mark.parametrize("relkey", [True, False])
+def test_self_attention_backward(pkg, hip, Fm, B, nh, L, P, relkey):
+    H = nh * 64
+    qkv = torch.randn(B * L, 3 * H, generator=g(L))
+    E = torch.randn(2 * P - 1, 64, generator=g(P)) if relkey else None
+    lens = torch.randint(1, L + 1, (B,), generator=g(3))
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    go = torch.randn(B * L, H, generator=g(9))
+    qr = leaf(qkv, dtype=torch.double)
+    Er = leaf(E, dtype=torch.double) if relkey else None
+    sp = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attention(sp(qr[:, :H]), sp(qr[:, H:2 * H]), sp(qr[:, 2 * H:]), mask.double(), Er, P)
+    ref.permute(0, 2, 1, 3).reshape(B * L, H).backward(go.double())
+    qd = leaf(qkv, DEV)
+    Ed = leaf(E, DEV) if relkey else None
+    out = Fm.attention(qd, None, B, nh, L, L, key_mask=mask.to(DEV), dist_emb=Ed, max_pos=P)
+    out.backward(go.to(DEV))
+    assert rel_err(qd.grad, qr.grad.float()) < 2e-5
+    if relkey:
+        assert rel_err(Ed.grad, Er.grad.float()) < 2e-5
+
+
+def test_cross_attention_backward_rectangular(pkg, hip, Fm):
+    B, nh, Lq, Lk = 2, 3, 40, 70
+    H = nh * 64
+    q, kv = torch.randn(B * Lq, H, generator=g(1)), torch.randn(B * Lk, 2 * H, generator=g(2))
+    mask = (torch.arange(Lk)[None] < torch.tensor([[70], [33]])).float()
+    go = torch.randn(B * Lq, H, generator=g(3))
+    qr, kr = leaf(q, dtype=torch.double), leaf(kv, dtype=torch.double)
+    sp = lambda x, L: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attention(sp(qr, Lq), sp(kr[:, :H], Lk), sp(kr[:, H:], Lk), mask.double(), None, 0)
+    ref.permute(0, 2, 1, 3).reshape(B * Lq, H).backward(go.double())
+    qd, kd = leaf(q, DEV), leaf(kv, DEV)
+    Fm.attention(qd, kd, B, nh, Lq, Lk, key_mask=mask.to(DEV)).backward(go.to(DEV))
+    assert rel_err(qd.grad, qr.grad.float()) < 2e-5
+    assert rel_err(kd.grad, kr.grad.float()) < 2e-5
+
+
+def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol):
+    model.zero_grad(set_to_none=True)
+    loss_dev.backward()
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_ref = loss_ref_fn(ref_sd)
+    loss_ref.backward()
+    assert loss_dev.item() == pytest.approx(loss_ref.item(), rel=2e-4)
+    worst = {}
+    # key biases have an exactly-zero gradient (softmax is invariant to a per-query shift of all
+    # scores), so their "reference" gradient is rounding noise: floor every denominator at 1e-3 of
+    # the typical gradient magnitude
+    scale = torch.stack([v.grad.abs().max() for v in ref_sd.values() if v.grad is not None]).median().item()
+    for k, p in model.named_parameters():
+        want = ref_sd[k].grad
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        worst[k] = ((p.grad.cpu() - want).abs().max() / max(want.abs().max().item(), 1e-3 * scale)).item()
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    return max(worst.values())
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-4), ("bf16x3", 2e-3)])
+def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, capsys):
+    """Whole structure model, loss of the reference (wrapped L1 x4 + smooth-L1 x4), every parameter
+    gradient against CPU autograd of the oracle."""
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion
+    L, B = 64, 3
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=2,
+             max_position_embeddings=L, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = ConditionalBertForDiffusion(
+        BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("abcdefgh"),
+        loss_func=[ConditionalBertForDiffusion.diheral_loss_func] * 4 + [ConditionalBertForDiffusion.angle_loss_func] * 4)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=12)
+    model.load_state_dict(sd)
+    model = model.train().to(DEV)
+    pk = synthetic_pockets(B, L, seed=5)
+    gen = g(1)
+    batch = dict(pk, timestep=torch.randint(0, 1000, (B, 1), generator=gen),
+                 noised_ligand_angle=ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=gen)),
+                 known_noise=ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=gen)))
+    dbatch = {k: v.to(DEV) for k, v in batch.items() if torch.is_tensor(v)}
+    prev = pkg.ops.set_gemm_mode(mode)
+    try:
+        loss = model.training_step(dbatch)
+
+        def ref_loss(rsd):
+            pred = ostr.forward(rsd, {"num_heads": 12, "max_pos": L}, batch["timestep"], batch["noised_ligand_angle"],
+                                pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
+            return ostr.loss_terms(pred, batch["known_noise"], pk["ligand_attn_mask"]).mean()
+
+        worst = _grad_compare(model, sd, loss, ref_loss, tol)
+    finally:
+        pkg.ops.set_gemm_mode(prev)
+    with capsys.disabled():
+        print(f"\n[structure grads, {mode}] worst relative gradient error {worst:.2e}")
+
+
+def test_sequence_training_step_gradients_match_oracle(pkg, hip, capsys):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    L, B = 64, 3
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=2,
+             max_position_embeddings=L, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = PeptideDiff(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True),
+                        feature_names=list("ACDEFGHIKLMNPQRSTVWY"), loss_func=torch.nn.CrossEntropyLoss(),
+                        noise_schedule="cosine", timesteps=50)
+    sd = seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=13)
+    model.load_state_dict(sd)
+    model = model.train().to(DEV)
+    pk = synthetic_pockets(B, L, seed=6, with_ligand_seq=True)
+    t_int = torch.tensor([[5.0], [30.0], [48.0]])
+    noised = oseq.apply_aa_noise(pk["ligand_seq"], t_int, oseq.NoiseScheduleDiscrete(50),
+                                 oseq.BlosumTransition(torch.load(__import__("os").path.join(
+                                     __import__("helpers").GOLDEN, "blosum_substitute.pt"), weights_only=True)),
+                                 u=torch.rand(B * L, generator=g(2)))
+    dpk = {k: v.to(DEV) for k, v in pk.items() if torch.is_tensor(v)}
+    prev = pkg.ops.set_gemm_mode("bf16x6")
+    try:
+        loss = model.get_loss(dpk, (t_int / 50).to(DEV), noised.to(DEV))[0]
+
+        def ref_loss(rsd):
+            pred = oseq.forward(rsd, {"num_heads": 12, "max_pos": L}, t_int / 50, noised, pk["ligand_angles"],
+                                pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
+            return oseq.get_loss(pred, pk, noised)[0]
+
+        worst = _grad_compare(model, sd, loss, ref_loss, 2e-4)
+    finally:
+        pkg.ops.set_gemm_mode(prev)
+    # parameters the forward never touches keep no gradient (reference quirk)
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("receptor_feature_emb."))
+    with capsys.disabled():
+        print(f"\n[sequence grads, bf16x6] worst relative gradient error {worst:.2e}")
