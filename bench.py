@@ -184,9 +184,11 @@ def main():
             for mode in pkg.ops.GEMM_MODES:
                 if mode != args.gemm_mode:
                     pkg.ops.set_gemm_mode(mode)
+                    pkg.ops.set_attn_mode(mode)
                     timed(full_step, 1)
                     by_mode[mode] = timed(full_step, max(1, args.steps // 2)) / max(1, args.steps // 2)
         pkg.ops.set_gemm_mode(args.gemm_mode)
+        pkg.ops.set_attn_mode(args.gemm_mode)
         timed(full_step, args.warmup)
         elapsed = timed(full_step, args.steps)
         by_mode[args.gemm_mode] = elapsed / args.steps
@@ -247,9 +249,11 @@ def main():
                        "pockets_per_gpu": B, "seq_len": L, "parallelism": f"pocket-sharded x{world}, no collective"},
             "model_tflops": structure_flops_per_pocket(L) * B * world * args.steps / elapsed / 1e12,
             "value_encoder_cached": B * world * args.steps / elapsed_cached,
-            "roofline": {"kernel": "attn_fwd_kernel<relkey> (e3d_relkey_attn_fwd)", "bound": "mfma",
-                         "achieved": a_tf, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": a_tf / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+            "roofline": {"kernel": ("attn_fwd_kernel<relkey> (e3d_relkey_attn_fwd)" if args.gemm_mode == "f32" else
+                                    f"attn_fwd_split_kernel<{args.gemm_mode}, relkey> (e3d_relkey_attn_fwd_split)"),
+                         "bound": "mfma", "achieved": a_tf, "peak": gemm_peak, "unit": "TFLOP/s (algorithmic 6 L^2 H)",
+                         "frac": a_tf / gemm_peak, "traffic": traffic,
+                         "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes",
                          "avg_launch_ms": attn_ms, "launches_per_step": n_attn,
                          "hbm_algorithmic_GBps": a_gb, "hbm_frac": a_gb / PEAK_HBM_GBPS},
             "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",

@@ -86,7 +86,20 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
     return out
 
 
-def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False):
+ATTN_MODE = os.environ.get("E3D_ATTN_MODE", GEMM_MODE)   # same choices and meaning as GEMM_MODE
+if ATTN_MODE not in GEMM_MODES:
+    raise ValueError(f"E3D_ATTN_MODE must be one of {sorted(GEMM_MODES)}, got {ATTN_MODE!r}")
+
+
+def set_attn_mode(mode):
+    global ATTN_MODE
+    if mode not in GEMM_MODES:
+        raise ValueError(f"attention mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+    prev, ATTN_MODE = ATTN_MODE, mode
+    return prev
+
+
+def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False, mode=None):
     """q [B*Lq, >=nh*64] / k, v [B*Lk, ...] row-strided 2-D views (e.g. slices of a fused QKV
     buffer).  Returns ctx [B*Lq, nh*64] (and lse [B,nh,Lq])."""
     for n, t in (("q", q), ("k", k), ("v", v), ("key_mask", key_mask), ("dist_emb", dist_emb)):
@@ -99,11 +112,15 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         assert dist_emb.is_contiguous() and dist_emb.shape == (2 * max_pos - 1, 64), dist_emb.shape
     out = torch.empty((B * Lq, nh * 64), device=q.device, dtype=torch.float32)
     lse = torch.empty((B, nh, Lq), device=q.device, dtype=torch.float32) if want_lse else None
+    terms = GEMM_MODES[ATTN_MODE if mode is None else mode]
     with _timed("attn_relkey" if dist_emb is not None else "attn_cross", (B, nh, Lq, Lk)):
-        hip.check(hip.lib().e3d_relkey_attn_fwd(
-            _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
-            _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
-            B, nh, Lq, Lk, _stream()), "e3d_relkey_attn_fwd")
+        args = (_p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
+                _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
+                B, nh, Lq, Lk)
+        if terms == 0:
+            hip.check(hip.lib().e3d_relkey_attn_fwd(*args, _stream()), "e3d_relkey_attn_fwd")
+        else:
+            hip.check(hip.lib().e3d_relkey_attn_fwd_split(*args, terms, _stream()), "e3d_relkey_attn_fwd_split")
     return (out, lse) if want_lse else out
 
 

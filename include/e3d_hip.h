@@ -65,6 +65,16 @@ int e3d_relkey_attn_fwd(const float* q, int64_t q_bs, int64_t q_rs,
                         const float* dist_emb, int P, const float* key_mask,
                         float* out, float* lse, int B, int nh, int Lq, int Lk, void* stream);
 
+/* Same contract as e3d_relkey_attn_fwd on the bf16 matrix cores: K, E, Q, V and the softmax
+ * probabilities enter the MFMAs as 2 (terms = 3) or 3 (terms = 6, fp32-grade) bf16 split terms,
+ * accumulation, softmax and the rel-key skew stay fp32. */
+int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
+                              const float* k, int64_t k_bs, int64_t k_rs,
+                              const float* v, int64_t v_bs, int64_t v_rs,
+                              const float* dist_emb, int P, const float* key_mask,
+                              float* out, float* lse, int B, int nh, int Lq, int Lk, int terms,
+                              void* stream);
+
 /* out[M,H] = LayerNorm_eps(x[M,H] (+ residual[M,H])) * gamma + beta
  * -- BertSelfOutput / BertOutput (4.38.2) with the dense bias already added by the GEMM,
  * and predictor.layer_norm (structure_model/model.py:152).  residual may be NULL.

@@ -74,7 +74,8 @@ def ref_attention(q, k, v, mask, E, P):
 @pytest.mark.parametrize("B,nh,L,P", [(2, 4, 16, 16), (1, 12, 64, 64), (3, 2, 50, 64), (2, 12, 128, 128),
                                       (1, 3, 256, 256), (2, 1, 33, 40)])
 @pytest.mark.parametrize("relkey", [True, False])
-def test_attention_self(pkg, hip, B, nh, L, P, relkey):
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4)])
+def test_attention_self(pkg, hip, B, nh, L, P, relkey, mode, tol):
     H = nh * 64
     qkv = torch.randn(B * L, 3 * H, generator=g(L))
     E = torch.randn(2 * P - 1, 64, generator=g(P + 1)) if relkey else None
@@ -83,17 +84,17 @@ def test_attention_self(pkg, hip, B, nh, L, P, relkey):
     mask = (torch.arange(L)[None] < lens[:, None]).float()
     dq = qkv.to(DEV)
     got, lse = pkg.ops.attention(dq[:, :H], dq[:, H:2 * H], dq[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),
-                                 dist_emb=None if E is None else E.to(DEV), max_pos=P, want_lse=True)
+                                 dist_emb=None if E is None else E.to(DEV), max_pos=P, want_lse=True, mode=mode)
     split = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
     q, k, v = split(qkv[:, :H]), split(qkv[:, H:2 * H]), split(qkv[:, 2 * H:])
     ref = ref_attention(q, k, v, mask.double(), None if E is None else E.double(), P)
     ref = ref.permute(0, 2, 1, 3).reshape(B * L, H).float()
-    assert rel_err(got, ref) < 1e-5
+    assert rel_err(got, ref) < tol
     s = q @ k.transpose(-1, -2)
     if E is not None:
         s = s + obert.relkey_scores_literal(q, E.double(), P)
     s = s / 8.0 + ((1.0 - mask.double()) * -10000.0)[:, None, None, :]
-    assert rel_err(lse, torch.logsumexp(s, -1).float()) < 1e-5
+    assert rel_err(lse, torch.logsumexp(s, -1).float()) < tol
 
 
 def test_attention_cross_rectangular_and_nomask(pkg, hip):
@@ -102,10 +103,11 @@ def test_attention_cross_rectangular_and_nomask(pkg, hip):
     qb = torch.randn(B * Lq, H, generator=g(1))
     kv = torch.randn(B * Lk, 2 * H, generator=g(2))
     dkv = kv.to(DEV)
-    got = pkg.ops.attention(qb.to(DEV), dkv[:, :H], dkv[:, H:], B, nh, Lq, Lk)
     sp = lambda x, L: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
     ref = ref_attention(sp(qb, Lq), sp(kv[:, :H], Lk), sp(kv[:, H:], Lk), None, None, 0)
-    assert rel_err(got, ref.permute(0, 2, 1, 3).reshape(B * Lq, H).float()) < 1e-5
+    for mode, tol in (("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4)):
+        got = pkg.ops.attention(qb.to(DEV), dkv[:, :H], dkv[:, H:], B, nh, Lq, Lk, mode=mode)
+        assert rel_err(got, ref.permute(0, 2, 1, 3).reshape(B * Lq, H).float()) < tol, mode
 
 
 def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):

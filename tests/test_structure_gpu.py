@@ -101,7 +101,7 @@ def test_forward_matches_oracle_full_width_with_relkey(pkg, hip, layers, B, L):
 
 
 def test_gemm_arithmetic_modes_end_to_end(pkg, hip, capsys):
-    """Full 12+12-layer model, L=128: exact fp32 MFMA vs bf16-split GEMM modes, all against the
+    """Full 12+12-layer model, L=128: exact fp32 MFMA vs bf16-split GEMM + attention modes, all against the
     oracle.  bf16x6 is fp32-grade; bf16x3 (the default) must stay inside the 1e-4 budget with margin."""
     cfg = dict(FULL_STRUCT, num_hidden_layers=12)
     B, L = 2, 128
@@ -114,12 +114,13 @@ def test_gemm_arithmetic_modes_end_to_end(pkg, hip, capsys):
     d = to_dev(pk)
     errs = {}
     for mode, bound in (("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", TOL / 2)):
-        prev = pkg.ops.set_gemm_mode(mode)
+        prev, prev_a = pkg.ops.set_gemm_mode(mode), pkg.ops.set_attn_mode(mode)
         try:
             got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
                         d["receptor_attn_mask"])
         finally:
             pkg.ops.set_gemm_mode(prev)
+            pkg.ops.set_attn_mode(prev_a)
         errs[mode] = rel_err(got, want)
         assert errs[mode] < bound, (mode, errs)
     with capsys.disabled():

@@ -57,13 +57,18 @@ def bench_attn():
         E = torch.randn(2 * L - 1, 64, device=DEV)
         mask = torch.ones(B, L, device=DEV)
         for name, e in (("relkey", E), ("plain", None)):
-            fn = lambda: ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,  # noqa: E731
-                                       dist_emb=e, max_pos=L)
-            ms = time_ms(fn)
-            fl = (6.0 if e is not None else 4.0) * L * L * H * B
-            by = (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B
-            print(f"attn {name:6s} B={B:5d} L={L:4d}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF  {by / ms / 1e6:7.1f} GB/s algorithmic",
-                  flush=True)
+            ref = None
+            for mode in ("f32", "bf16x3", "bf16x6"):
+                fn = lambda: ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,  # noqa: E731
+                                           dist_emb=e, max_pos=L, mode=mode)
+                out = fn()
+                ref = out if ref is None else ref
+                err = ((out - ref).abs().max() / ref.abs().max()).item()
+                ms = time_ms(fn)
+                fl = (6.0 if e is not None else 4.0) * L * L * H * B
+                by = (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B
+                print(f"attn {name:6s} {mode:6s} B={B:5d} L={L:4d}: {ms:7.3f} ms  {fl / ms / 1e9:6.1f} TF  "
+                      f"{by / ms / 1e6:7.1f} GB/s algorithmic  rel diff vs f32 kernel {err:.1e}", flush=True)
 
 
 def attn_pmc():
