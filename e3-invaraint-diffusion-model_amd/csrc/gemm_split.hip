@@ -206,9 +206,170 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-M forward variant: 256x256x32 workgroup tile, 8 waves as 2(M) x 4(N), each wave 128x64
+// (4x2 MFMA tiles, 128 accumulator registers).  Versus the 256x128 kernel it moves 2/3 of the
+// global->LDS bytes and 3/4 of the LDS fragment bytes per flop.  LDS rows are unpadded 64 bytes
+// (so that two buffers of 2 x 512 rows fit) with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3:
+// the 16 lanes of a ds_read_b128 group (4 row quads) then hit 16 distinct 4-bank slots.
+constexpr int BT = 256, ROW64 = 64;
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int NS, int ACT>
+__global__ __launch_bounds__(512) void gemm_split256_kernel(const float* __restrict__ A, int64_t lda,
+                                                            const float* __restrict__ W,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ out, int64_t ldc, int M, int N,
+                                                            int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NBUF = NS == 2 ? 2 : 1;
+    constexpr int T_BYTES = BT * ROW64;            // one operand, one part
+    constexpr int BUF_BYTES = 2 * NS * T_BYTES;    // A parts then B parts
+
+    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = lid / tiles_n, tn = lid % tiles_n;
+    const int row0 = tm * BT, col0 = tn * BT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;   // 2 x 4 waves
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // staging: float4 f = tid + 512 i -> row f>>3, k-group f&7 (4 floats); 4 per operand per thread
+    const float* a_src[4];
+    const float* b_src[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 512 * i, r = f >> 3, kg = f & 7;
+        int ar = row0 + r;
+        ar = ar < M ? ar : M - 1;
+        a_src[i] = A + (int64_t)ar * lda + kg * 4;
+        b_src[i] = W + (int64_t)(col0 + r) * K + kg * 4;
+        lds_off[i] = swz_off(r, kg >> 1) + (kg & 1) * 8;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    auto g_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
+            rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * BK);
+        }
+    };
+    auto lds_store = [&](unsigned char* base) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 pa[NS], pb[NS];
+            split4<NS>(ra[i], pa);
+            split4<NS>(rb[i], pb);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                *reinterpret_cast<bf16x4*>(base + s * T_BYTES + lds_off[i]) = pa[s];
+                *reinterpret_cast<bf16x4*>(base + (NS + s) * T_BYTES + lds_off[i]) = pb[s];
+            }
+        }
+    };
+    g_load(0);
+    lds_store(smem_raw);
+    __syncthreads();
+
+    const int nk = K / BK;
+    int a_row[4], b_row[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_row[m] = wr * 128 + m * 32 + l31;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b_row[n] = wc * 64 + n * 32 + l31;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) g_load(kt + 1);
+        const unsigned char* base = smem_raw + cur * BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[NS][4], fb[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    fb[s][n] = *reinterpret_cast<const bf16x8*>(base + (NS + s) * T_BYTES + swz_off(b_row[n], 2 * ks + half));
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (NS == 3) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[NS - 1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                }
+        }
+        if (NBUF == 2) {
+            if (more) lds_store(smem_raw + (cur ^ 1) * BUF_BYTES);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) lds_store(smem_raw);
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int col = col0 + wc * 64 + n * 32 + l31;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wr * 128 + m * 32 + mfma32_row(r, half);
+                float v = acc[m][n][r] + bv;
+                if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
+                if (ACT == E3D_ACT_SILU) v = silu(v);
+                if (row < M) out[(int64_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int NS, int ACT>
+int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
+              int K, hipStream_t s) {
+    const int tiles_m = (M + BT - 1) / BT, tiles_n = N / BT;
+    constexpr int NBUF = NS == 2 ? 2 : 1;
+    const size_t lds = (size_t)NBUF * 2 * NS * BT * ROW64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256_kernel<NS, ACT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, A, lda, W, bias, out,
+                       ldc, M, N, K, tiles_m, tiles_n);
+    return e3d_launch_status("e3d_gemm_f32_split (256x256)");
+}
+
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
            int M, int N, int K, hipStream_t s) {
+    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K &&
+        (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
+        return launch256<NS, ACT>(A, lda, B, bias, out, ldc, M, N, K, s);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;

@@ -94,40 +94,39 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(
     const float* __restrict__ post_add, int rows_per_add, float* __restrict__ z_out,
     float* __restrict__ out, int M) {
     constexpr int H = 256 * V;
+    // W^T [F][H] lives in LDS for the whole workgroup (W is [H][F]: reading it per row straight from
+    // global memory is a stride-F gather); each wave then walks rows wave, wave + n_waves, ...
+    extern __shared__ __attribute__((aligned(16))) float wt[];
+    for (int i = threadIdx.x; i < H * F; i += blockDim.x) wt[(i % F) * H + i / F] = W[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float xin[32];
-    const float* xr = x + (int64_t)row * F;
-#pragma unroll
-    for (int f = 0; f < 32; ++f) xin[f] = f < F ? xr[f] : 0.f;
-    f32x4 r[V];
-    row_load<V>(r, bias, lane);
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* w = W + (int64_t)(4 * (64 * i + lane) + j) * F;
-            float acc = 0.f;
-#pragma unroll
-            for (int f = 0; f < 32; ++f)  // static register indices; F is wave-uniform
-                if (f < F) acc = fmaf(xin[f], w[f], acc);
-            r[i][j] += acc;
-        }
-    if (z_out) row_store<V>(r, z_out + (int64_t)row * H, lane);  // pre-LayerNorm activations for the backward
-    row_normalize<V>(r, eps);
-    f32x4 g[V], b[V];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    f32x4 g[V], b[V], bs[V];
     row_load<V>(g, gamma, lane);
     row_load<V>(b, beta, lane);
+    row_load<V>(bs, bias, lane);
+    for (int row = wave; row < M; row += n_waves) {
+        const float* xr = x + (int64_t)row * F;
+        f32x4 r[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) r[i] = r[i] * g[i] + b[i];
-    if (post_add) {
-        f32x4 a[V];
-        row_load<V>(a, post_add + (int64_t)(row / rows_per_add) * H, lane);
+        for (int i = 0; i < V; ++i) r[i] = bs[i];
+        for (int f = 0; f < F; ++f) {
+            const float xv = xr[f];
 #pragma unroll
-        for (int i = 0; i < V; ++i) r[i] += a[i];
+            for (int i = 0; i < V; ++i) r[i] += xv * *reinterpret_cast<const f32x4*>(wt + f * H + 4 * (64 * i + lane));
+        }
+        if (z_out) row_store<V>(r, z_out + (int64_t)row * H, lane);  // pre-LayerNorm rows for the backward
+        row_normalize<V>(r, eps);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = r[i] * g[i] + b[i];
+        if (post_add) {
+            f32x4 a[V];
+            row_load<V>(a, post_add + (int64_t)(row / rows_per_add) * H, lane);
+#pragma unroll
+            for (int i = 0; i < V; ++i) r[i] += a[i];
+        }
+        row_store<V>(r, out + (int64_t)row * H, lane);
     }
-    row_store<V>(r, out + (int64_t)row * H, lane);
 }
 
 template <int V>
@@ -195,9 +194,21 @@ extern "C" int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, co
     E3D_REQUIRE(x && W && b && gamma && beta && out && M > 0, "embed_layernorm: bad arguments");
     E3D_REQUIRE(F >= 1 && F <= 32, "embed_layernorm: F must be in [1,32] (F=%d)", F);
     E3D_REQUIRE(!post_add || rows_per_add >= 1, "embed_layernorm: rows_per_add=%d", rows_per_add);
-    const dim3 grid((M + 3) / 4), block(256);
-    DISPATCH_V(H, hipLaunchKernelGGL(embed_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x, F, W, b,
-                                     gamma, beta, eps, post_add, rows_per_add, z_out, out, M));
+    // every workgroup re-stages W^T (F*H*4 bytes of LDS): cap the grid so each one amortises it over >= 32 rows
+    int blocks = (M + 127) / 128;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    const dim3 grid(blocks), block(256);
+    const size_t lds = (size_t)F * H * sizeof(float);
+    DISPATCH_V(H, {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_layernorm_kernel<V>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32 * H * (int)sizeof(float));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(embed_layernorm_kernel<V>, grid, block, lds, (hipStream_t)stream, x, F, W, b, gamma, beta,
+                           eps, post_add, rows_per_add, z_out, out, M);
+    });
     return e3d_launch_status("e3d_embed_layernorm_fwd");
 }
 

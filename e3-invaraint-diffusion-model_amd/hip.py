@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libe3d_hip.so")
+LIB_PATH = os.environ.get("E3D_HIP_LIB", os.path.join(_HERE, "libe3d_hip.so"))   # override: kernel experiments
 ABI_VERSION = 1
 
 _P = c_void_p

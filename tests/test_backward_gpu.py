@@ -199,7 +199,10 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         assert p.grad is not None, k
-        worst[k] = ((p.grad.cpu() - want).abs().max() / max(want.abs().max().item(), 1e-3 * scale)).item()
+        if k.endswith("self.key.bias"):      # mathematically zero: only check that it is noise-sized
+            assert float(p.grad.abs().max()) < 1e-2 * scale, k
+            continue
+        worst[k] =((p.grad.cpu() - want).abs().max() / max(want.abs().max().item(), 1e-3 * scale)).item()
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     return max(worst.values())
