@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq,
-    int Lk, int q_tiles, int n_units) {
+    int Lk, int q_tiles, int n_units, int skip_padded_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qi = lane & 31, half = lane >> 5;
@@ -180,7 +180,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
         for (int r = 0; r < 16; ++r) ring[(32 + mfma32_row(r, half)) * RING_LD + qi] = t[r];
     }
 
-    const int k_tiles = (Lk + 31) >> 5;
+    // Trailing key tiles that are padding in every position contribute exp(-10000 - m) == 0.0f exactly
+    // (fp32 underflow), so the sweep stops after the tile of the last valid key.  The result is bit-identical
+    // to the full sweep; an all-padding item (no valid key) keeps the full sweep, as the reference then
+    // softmaxes the uniformly shifted scores.
+    int k_tiles = (Lk + 31) >> 5;
+    if (mb && skip_padded_tiles) {
+        int last = -1;
+        for (int base = 0; base < Lk; base += 64) {
+            const int key = base + lane;
+            const bool valid = key < Lk && mb[key] != 0.f;
+            const unsigned long long bits = __ballot(valid);
+            if (bits) last = base + 63 - __builtin_clzll(bits);
+        }
+        if (last >= 0) k_tiles = (last >> 5) + 1;
+    }
     for (int kt = 0; kt < k_tiles; ++kt) {
         const int r0 = kt * 32;
         TileRegs kreg, ereg;
@@ -279,6 +293,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     }
 }
 
+int g_skip_padded = 1;
+
 template <int NS>
 int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
            int64_t v_bs, int64_t v_rs, const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
@@ -290,14 +306,20 @@ int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k
     const size_t lds = (size_t)wpb * WAVE_LDS_F * sizeof(float);
     if (dist_emb)
         hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units);
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded);
     else
         hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units);
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded);
     return e3d_launch_status("e3d_relkey_attn_fwd_split");
 }
 
 }  // namespace
+
+extern "C" int e3d_attn_skip_padded_tiles(int enable) {
+    const int prev = g_skip_padded;
+    g_skip_padded = enable ? 1 : 0;
+    return prev;
+}
 
 extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                          int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,

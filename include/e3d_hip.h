@@ -75,6 +75,12 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
                               float* out, float* lse, int B, int nh, int Lq, int Lk, int terms,
                               void* stream);
 
+/* Process-wide switch of the split attention kernels (default 1): stop the key sweep after the tile
+ * holding the last valid key of the item.  Trailing all-padding tiles contribute exp(-10000 - m) = 0.0f
+ * exactly, so results are bit-identical; 0 restores the dense sweep (timing comparisons).  Returns the
+ * previous setting. */
+int e3d_attn_skip_padded_tiles(int enable);
+
 /* out[M,H] = LayerNorm_eps(x[M,H] (+ residual[M,H])) * gamma + beta
  * -- BertSelfOutput / BertOutput (4.38.2) with the dense bias already added by the GEMM,
  * and predictor.layer_norm (structure_model/model.py:152).  residual may be NULL.

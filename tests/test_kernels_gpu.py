@@ -125,6 +125,34 @@ def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):
     assert rel_err(a, torch.softmax(s, -1) @ v) < 5e-3
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_attention_padded_tile_skipping_is_bit_exact(pkg, hip, mode):
+    """Stopping the key sweep after the last valid key's tile must not change a single bit
+    (trailing padding tiles contribute exp(-10000 - m) == 0), incl. masks with holes and an
+    all-padding item (which must keep the dense sweep)."""
+    B, nh, L, P = 4, 2, 256, 256
+    H = nh * 64
+    qkv = (torch.randn(B * L, 3 * H, generator=g(1)) * 1.5).to(DEV)
+    E = torch.randn(2 * P - 1, 64, generator=g(2)).to(DEV)
+    mask = torch.zeros(B, L)
+    mask[0, :37] = 1
+    mask[1, :200] = 1
+    mask[1, 50:90] = 0           # hole
+    mask[2, :] = 1
+    # item 3: no valid key at all
+    mask = mask.to(DEV)
+    outs = []
+    for enable in (1, 0):
+        prev = hip.e3d_attn_skip_padded_tiles(enable)
+        try:
+            outs.append(pkg.ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,
+                                          dist_emb=E, max_pos=P, want_lse=True, mode=mode))
+        finally:
+            hip.e3d_attn_skip_padded_tiles(prev)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()
+
+
 def test_attention_rejects_relkey_longer_than_table(pkg, hip):
     d = torch.zeros(80, 192, device=DEV)
     with pytest.raises(RuntimeError, match="relative_key"):
