@@ -26,6 +26,7 @@ _SIGNATURES = {
     "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "e3d_adaln_gate_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "e3d_embed_layernorm_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, c_float, _P, c_int, _P, _P, c_int, c_int, _P]),
+    "e3d_nerf_backbone": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     # training (backward) side
     "e3d_gemm_f32_split_general": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, c_int64, c_int, c_int,
                                            c_int, c_int, c_int, _P]),

@@ -143,6 +143,14 @@ int e3d_discrete_posterior_sample(const int32_t* xt_idx, const float* logits, co
 int e3d_discrete_q_sample(const int32_t* x0_idx, const float* Qtb, const float* u, int mode,
                           int32_t* out_idx, int B, int L, int C, void* stream);
 
+/* NeRF backbone builder, the step after structure sampling (structure_model/create_pdb.py:104-155,
+ * 175-234): angles [B,L,8] fp32 in the dataset's column order
+ * (phi psi omega dihedral_o tau CA:C:1N 1C:N:CA CA:C:O), lengths int32 [B] -> coords float64
+ * [B,L,4,3] (N, CA, C, O per residue; residues >= length zeroed), optionally centred per pocket
+ * (NERFBuilder.centered_cartesian_coords).  Bond lengths are the reference's constants. */
+int e3d_nerf_backbone(const float* angles, const int32_t* lengths, double* coords, int center,
+                      int B, int L, void* stream);
+
 /* ------------------------------------------------------------------ training (backward) side
  * The reference trains through torch.autograd on these same modules (Lightning training_step,
  * structure_model/model.py:305-319, sequence_model/model.py:347-367); the entry points below are
