@@ -97,12 +97,18 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M,
-                                                         int N, int K, int tiles_m, int tiles_n) {
+                                                         int N, int K_total, int tiles_m, int tiles_n,
+                                                         int k_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NBUF = NS == 2 ? 2 : 1;
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
     constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
 
+    // split-K (weight gradients: few output tiles, long reduction over the tokens): block y reduces
+    // k in [k_begin, K) and adds its partial tile atomically into the zero-initialised output
+    const int k_begin = blockIdx.y * k_chunk;
+    const int K = min(K_total, k_begin + k_chunk);
+    const bool split = gridDim.y > 1;
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
@@ -125,21 +131,21 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     f32x4 ra[Stager<BM, A_KMAJ>::NV], rb[Stager<BN, B_KMAJ>::NV];
-    sa.load(ra, 0, K);
-    sb.load(rb, 0, K);
+    sa.load(ra, k_begin, K);
+    sb.load(rb, k_begin, K);
     sa.template store<NS>(ra, smem_raw, A_BYTES);
     sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES);
     __syncthreads();
 
-    const int nk = (K + BK - 1) / BK;
+    const int nk = (K - k_begin + BK - 1) / BK;
     const int a_frag = (wr * 64 + l31) * ROW_B + half * 16;
     const int b_frag = (wc * 64 + l31) * ROW_B + half * 16;
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
-            sa.load(ra, (kt + 1) * BK, K);
-            sb.load(rb, (kt + 1) * BK, K);
+            sa.load(ra, k_begin + (kt + 1) * BK, K);
+            sb.load(rb, k_begin + (kt + 1) * BK, K);
         }
         const unsigned char* ab = smem_raw + cur * BUF_BYTES + a_frag;
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES + b_frag;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = col0 + wc * 64 + n * 32 + l31;
-        const float bv = (bias && col < N) ? bias[col] : 0.f;
+        const float bv = (bias && col < N && blockIdx.y == 0) ? bias[col] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -200,7 +206,10 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
                 float v = acc[m][n][r] + bv;
                 if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                 if (ACT == E3D_ACT_SILU) v = silu(v);
-                if (row < M && col < N) out[(int64_t)row * ldc + col] = v;
+                if (row < M && col < N) {
+                    if (split) atomicAdd(out + (int64_t)row * ldc + col, v);
+                    else out[(int64_t)row * ldc + col] = v;
+                }
             }
         }
     }
@@ -379,8 +388,27 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>), dim3(tiles_m * tiles_n), dim3(512), lds, s, A,
-                       lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n);
+    // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count
+    int splits = 1;
+    if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 128 && K >= 1024) {
+        splits = 256 / (tiles_m * tiles_n);
+        splits = splits > 16 ? 16 : splits;
+        while (splits > 1 && K / splits < 256) --splits;
+    }
+    int k_chunk = K;
+    if (splits > 1) {
+        k_chunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+        splits = (K + k_chunk - 1) / k_chunk;
+        hipError_t e = hipSuccess;
+        if (ldc == N) e = hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), s);
+        else e = hipMemset2DAsync(out, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+        if (e != hipSuccess) {
+            e3d_set_error("gemm_split: split-K memset failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>), dim3(tiles_m * tiles_n, splits), dim3(512), lds, s,
+                       A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
     return e3d_launch_status("e3d_gemm_f32_split");
 }
 

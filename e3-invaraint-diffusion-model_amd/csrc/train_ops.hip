@@ -66,8 +66,8 @@ __device__ __forceinline__ void ln_input_grad(f32x4 (&g)[V], const f32x4 (&xhat)
 }
 
 // ---------------------------------------------------------------- LayerNorm backward
-// Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partials stay in registers and
-// are added once per wave (float atomics: order-dependent in the last bits).
+// Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partials stay in registers, are
+// summed over the block in LDS and added once per block (float atomics: order-dependent last bits).
 template <int V>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
                                                             const float* __restrict__ s,
@@ -95,8 +95,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         ln_input_grad<V>(g, x, rstd);
         row_store<V>(g, ds + (int64_t)row * H, lane);
     }
-    if (dgamma) row_atomic_add<V>(acc_g, dgamma, lane);
-    if (dbeta) row_atomic_add<V>(acc_b, dbeta, lane);
+    // the block's 4 waves reduce through LDS first: one atomic per column per block
+    __shared__ float red[4][2][H];
+    const int w = threadIdx.x >> 6;
+    row_store<V>(acc_g, red[w][0], lane);
+    row_store<V>(acc_b, red[w][1], lane);
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256) {
+        const int which = c / H, col = c - which * H;
+        float* dst = which ? dbeta : dgamma;
+        if (dst) atomicAdd(dst + col, red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col]);
+    }
 }
 
 // ---------------------------------------------------------------- adaLN gate backward
@@ -258,7 +267,7 @@ extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* g
     if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
     if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
     E3D_REQUIRE(e == hipSuccess, "layernorm_bwd: memset failed: %s", hipGetErrorString(e));
-    const int blocks = (M + 3) / 4 < 256 ? (M + 3) / 4 : 256;
+    const int blocks = (M + 15) / 16 < 512 ? (M + 15) / 16 : 512;
     DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s,
                                      gamma, eps, ds, dgamma, dbeta, M));
     return e3d_launch_status("e3d_layernorm_bwd");
@@ -291,7 +300,10 @@ extern "C" int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, 
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
     E3D_REQUIRE(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
-    const int rpb = 128;
+    // ~1024 blocks of 256 columns x rpb rows
+    const int col_blocks = (N + 255) / 256;
+    int rpb = (int)(((int64_t)M * col_blocks + 1023) / 1024);
+    rpb = rpb < 16 ? 16 : rpb;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, x, ld, out, M, N, rpb);
     return e3d_launch_status("e3d_colsum");
 }

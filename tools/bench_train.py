@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Training-step timings on one GPU (BASELINE configs 2 and 4, per-GPU part): full-size models,
+synthetic BioLiP-shaped batches, forward + loss + backward + grad-clip + AdamW.
+
+    python tools/bench_train.py [structure|sequence] [--batch B] [--seq-len L] [--steps K]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__  # noqa: E402
+
+pkg = __graft_entry__.load_package()
+from helpers import synthetic_pockets  # noqa: E402
+from e3diff_amd.bert import BertConfig  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", nargs="?", default="structure", choices=["structure", "sequence"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=8)
+    args = ap.parse_args()
+    L = args.seq_len
+    layers = 12 if args.model == "structure" else 6
+    B = args.batch or (32 if args.model == "structure" else 64)
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=layers,
+             max_position_embeddings=L, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    enc, dec = BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True)
+    torch.manual_seed(0)
+    if args.model == "structure":
+        from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as M
+        from e3diff_amd.structure_model.dataset import noise_batch_on_device
+        from e3diff_amd.structure_model.utils import CosineTables
+        model = M(enc, dec, feature_names=list("abcdefgh"), loss_func=[M.diheral_loss_func] * 4 + [M.angle_loss_func] * 4,
+                  l2_lambda=0.1)
+        tab = CosineTables(1000)
+    else:
+        from e3diff_amd.sequence_model.model import PeptideDiff as M
+        model = M(enc, dec, feature_names=list("ACDEFGHIKLMNPQRSTVWY"), loss_func=torch.nn.CrossEntropyLoss(),
+                  noise_schedule="cosine", timesteps=50, l2_lambda=0.1)
+    model = model.train().to(DEV)
+    optim = model.configure_optimizers()["optimizer"]
+    params = [p for p in model.parameters() if p.requires_grad]
+    pk = {k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=0, with_ligand_seq=True).items() if torch.is_tensor(v)}
+
+    def step():
+        if args.model == "structure":
+            batch = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab))
+        else:
+            batch = pk
+        loss = model.training_step(batch)
+        optim.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        optim.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    nparam = sum(p.numel() for p in params)
+    print(f"{args.model} training step: B={B} L={L} layers={layers} params={nparam / 1e6:.1f}M gemm_mode={pkg.ops.GEMM_MODE}: "
+          f"{dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s (loss {float(loss.detach()):.4f}, peak mem "
+          f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
