@@ -223,38 +223,78 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
 // the 16 lanes of a ds_read_b128 group (4 row quads) then hit 16 distinct 4-bank slots.
 constexpr int BT = 256, ROW64 = 64;
 
+#ifdef E3D_STAMPS   // lab builds only (tools/lab_gemm_stamps.py): in-kernel phase time stamps of one workgroup
+__device__ long long e3d_stamps[2][32][8];
+#define STAMP(slot)                                                                              \
+    do {                                                                                         \
+        if (stamp_on && kt < 32 && lane == 0) e3d_stamps[wr][kt][slot] = __builtin_readcyclecounter(); \
+    } while (0)
+#define STAMP_K(i)                                                                               \
+    do {                                                                                         \
+        if (blockIdx.x == 300 && (threadIdx.x & 255) == 0) e3d_stamps[threadIdx.x >> 8][i][7] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_K(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int NS, int ACT>
-__global__ __launch_bounds__(512) void gemm_split256_kernel(const float* __restrict__ A, int64_t lda,
-                                                            const float* __restrict__ W,
-                                                            const float* __restrict__ bias,
-                                                            float* __restrict__ out, int64_t ldc, int M, int N,
-                                                            int K, int tiles_m, int tiles_n) {
+// WR x WC waves, each 128x64: <2,4> = 256x256 tile, 512 threads, two LDS buffers, one block per CU;
+// <2,2> = 256x128 tile, 256 threads, ONE LDS buffer (48 KB) so that two blocks share a CU.
+//
+// PIPE (two buffers): the staging of tile t+1 is spread over the 8 MFMA groups of iteration t instead
+// of being one phase at its end.  In-kernel time stamps showed the classic loop as a serial sum --
+// ~2000 cycles for the 8 waves to push their 64 KB of global loads through the texture-address unit,
+// ~2400 of MFMA + fragment reads, ~1400 of split + LDS writes, barrier -- with the matrix pipe idle
+// in two of the three.  Here each MFMA group is preceded by 1/8 of the staging: split + ds_write of
+// one register item of tile t+1 (loaded during iteration t-1), then the re-issue of that item's
+// global load for tile t+2 (one register set, distance 2), so loads, VALU and LDS writes all run
+// under the MFMAs of the other wave of the SIMD.
+template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE>
+__global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const float* __restrict__ A, int64_t lda,
+                                                                        const float* __restrict__ W,
+                                                                        const float* __restrict__ bias,
+                                                                        float* __restrict__ out, int64_t ldc,
+                                                                        int M, int N, int K, int tiles_m,
+                                                                        int tiles_n) {
+    static_assert(!PIPE || NBUF == 2, "PIPE needs two LDS buffers");
+    STAMP_K(0);   // kernel entry
+#ifdef E3D_STAGGER   // lab: phase-shift the CUs of an XCD so that their output bursts do not coincide
+    if (PIPE && blockIdx.x < 256) {
+        const int g = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(E3D_STAGGER);
+    }
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int NBUF = NS == 2 ? 2 : 1;
-    constexpr int T_BYTES = BT * ROW64;            // one operand, one part
-    constexpr int BUF_BYTES = 2 * NS * T_BYTES;    // A parts then B parts
+    constexpr int NT = WR * WC * 64, TM = WR * 128, TN = WC * 64;
+    constexpr int A_BYTES = TM * ROW64, B_BYTES = TN * ROW64;   // one operand, one part
+    constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);         // A parts then B parts
+    constexpr int NA = TM * 8 / NT, NB = TN * 8 / NT;           // float4 items per thread
+    constexpr int NI = NA + NB;
 
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid % tiles_n;
-    const int row0 = tm * BT, col0 = tn * BT;
+    const int row0 = tm * TM, col0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 2, wc = wid & 3;   // 2 x 4 waves
+    const int wr = wid / WC, wc = wid % WC;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // staging: float4 f = tid + 512 i -> row f>>3, k-group f&7 (4 floats); 4 per operand per thread
-    const float* a_src[4];
-    const float* b_src[4];
-    int lds_off[4];
+    // staging items: float4 f = tid + NT i -> row f>>3, k-group f&7 (4 floats); items [0, NA) are A's
+    const float* src[NI];
+    int dst[NI];   // byte offset of the item's first part inside a buffer
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 512 * i, r = f >> 3, kg = f & 7;
-        int ar = row0 + r;
-        ar = ar < M ? ar : M - 1;
-        a_src[i] = A + (int64_t)ar * lda + kg * 4;
-        b_src[i] = W + (int64_t)(col0 + r) * K + kg * 4;
-        lds_off[i] = swz_off(r, kg >> 1) + (kg & 1) * 8;
+    for (int i = 0; i < NI; ++i) {
+        const bool is_a = i < NA;
+        const int f = tid + NT * (is_a ? i : i - NA), r = f >> 3, kg = f & 7;
+        if (is_a) {
+            int ar = row0 + r;
+            ar = ar < M ? ar : M - 1;
+            src[i] = A + (int64_t)ar * lda + kg * 4;
+        } else {
+            src[i] = W + (int64_t)(col0 + r) * K + kg * 4;
+        }
+        dst[i] = (is_a ? 0 : NS * A_BYTES) + swz_off(r, kg >> 1) + (kg & 1) * 8;
     }
 
     f32x16 acc[4][2];
@@ -265,56 +305,75 @@ __global__ __launch_bounds__(512) void gemm_split256_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    f32x4 ra[4], rb[4];
-    auto g_load = [&](int kt) {
+    f32x4 rg[NI];
+    auto item_load = [&](int i, int kt) { rg[i] = *reinterpret_cast<const f32x4*>(src[i] + kt * BK); };
+    auto item_store = [&](int i, unsigned char* buf) {
+        bf16x4 p[NS];
+        split4<NS>(rg[i], p);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
-            rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kt * BK);
-        }
+        for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<bf16x4*>(buf + s * (i < NA ? A_BYTES : B_BYTES) + dst[i]) = p[s];
     };
-    auto lds_store = [&](unsigned char* base) {
+
+    STAMP_K(1);   // addressing done
+    const int nk = K / BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x4 pa[NS], pb[NS];
-            split4<NS>(ra[i], pa);
-            split4<NS>(rb[i], pb);
+    for (int i = 0; i < NI; ++i) item_load(i, 0);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                *reinterpret_cast<bf16x4*>(base + s * T_BYTES + lds_off[i]) = pa[s];
-                *reinterpret_cast<bf16x4*>(base + (NS + s) * T_BYTES + lds_off[i]) = pb[s];
-            }
-        }
-    };
-    g_load(0);
-    lds_store(smem_raw);
+    for (int i = 0; i < NI; ++i) item_store(i, smem_raw);
+    if (PIPE) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) item_load(i, nk > 1 ? 1 : 0);
+    }
     __syncthreads();
 
-    const int nk = K / BK;
     int a_row[4], b_row[2];
 #pragma unroll
     for (int m = 0; m < 4; ++m) a_row[m] = wr * 128 + m * 32 + l31;
 #pragma unroll
     for (int n = 0; n < 2; ++n) b_row[n] = wc * 64 + n * 32 + l31;
+    STAMP_K(2);   // prologue done (first tile staged)
     int cur = 0;
+#ifdef E3D_STAMPS
+    const bool stamp_on = blockIdx.x == 300 && (wid & 3) == 0;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) g_load(kt + 1);
+        STAMP(0);
+        if (!PIPE && more) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) item_load(i, kt + 1);
+        }
+        STAMP(1);
         const unsigned char* base = smem_raw + cur * BUF_BYTES;
+        unsigned char* next = smem_raw + (cur ^ 1) * BUF_BYTES;
+        // PIPE: tile kt+1 sits in rg[]; tile kt+2 (clamped: the last two iterations re-load and
+        // re-stage the last tile into the buffer nobody reads again) replaces it item by item
+        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[NS][4], fb[NS][2];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
-#pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    fb[s][n] = *reinterpret_cast<const bf16x8*>(base + (NS + s) * T_BYTES + swz_off(b_row[n], 2 * ks + half));
+                    fb[s][n] = *reinterpret_cast<const bf16x8*>(base + NS * A_BYTES + s * B_BYTES +
+                                                                swz_off(b_row[n], 2 * ks + half));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * A_BYTES + swz_off(a_row[m], 2 * ks + half));
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                if (PIPE) {
+                    const int g = ks * 4 + m;   // MFMA group 0..7 of this iteration
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        if (i * 8 / NI == g) {
+                            item_store(i, next);
+                            item_load(i, kt2);
+                        }
+                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     if (NS == 3) {
@@ -326,18 +385,39 @@ __global__ __launch_bounds__(512) void gemm_split256_kernel(const float* __restr
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
                 }
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
+            }
+            STAMP(2 + ks);   // MFMAs of this k-step issued
         }
-        if (NBUF == 2) {
-            if (more) lds_store(smem_raw + (cur ^ 1) * BUF_BYTES);
+        if (PIPE) {
+            STAMP(5);
             __syncthreads();
+            STAMP(6);
+            cur ^= 1;
+        } else if (NBUF == 2) {
+#ifdef E3D_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(4);        // next tile's global loads landed
+#endif
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) item_store(i, next);
+            }
+            STAMP(5);        // split + LDS writes issued
+            __syncthreads();
+            STAMP(6);
             cur ^= 1;
         } else {
             __syncthreads();
-            if (more) lds_store(smem_raw);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) item_store(i, smem_raw);
+            }
             __syncthreads();
         }
     }
 
+    STAMP_K(3);   // k loop done
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = col0 + wc * 64 + n * 32 + l31;
@@ -354,31 +434,48 @@ __global__ __launch_bounds__(512) void gemm_split256_kernel(const float* __restr
             }
         }
     }
+    STAMP_K(4);   // stores issued
+#ifdef E3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_K(5);   // stores retired
+#endif
 }
 
-template <int NS, int ACT>
+int g_tile_pref = -1;  // E3D_GEMM_TILE (experiments): 0 = 256x128 (8 waves of 64x64), 1 = 256x256 classic loop,
+                       // 2 = 256x128 two blocks per CU, 3 = 256x256 with interleaved staging (default)
+
+template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE = false>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
               int K, hipStream_t s) {
-    const int tiles_m = (M + BT - 1) / BT, tiles_n = N / BT;
-    constexpr int NBUF = NS == 2 ? 2 : 1;
-    const size_t lds = (size_t)NBUF * 2 * NS * BT * ROW64;
+    constexpr int TM = WR * 128, TN = WC * 64;
+    const int tiles_m = (M + TM - 1) / TM, tiles_n = N / TN;
+    const size_t lds = (size_t)NBUF * NS * (TM + TN) * ROW64;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256_kernel<NS, ACT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT>), dim3(tiles_m * tiles_n), dim3(512), lds, s, A, lda, W, bias, out,
-                       ldc, M, N, K, tiles_m, tiles_n);
-    return e3d_launch_status("e3d_gemm_f32_split (256x256)");
+    hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>), dim3(tiles_m * tiles_n), dim3(WR * WC * 64), lds, s,
+                       A, lda, W, bias, out, ldc, M, N, K, tiles_m, tiles_n);
+    return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
            int M, int N, int K, hipStream_t s) {
-    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K &&
+    if (g_tile_pref < 0) {
+        const char* e = getenv("E3D_GEMM_TILE");
+        g_tile_pref = e ? atoi(e) : 3;
+    }
+    if (!A_KMAJ && !B_KMAJ && ldb == K && g_tile_pref == 2 && N % 128 == 0 && NS == 2)
+        return launch256<NS, ACT, 2, 2, 1>(A, lda, B, bias, out, ldc, M, N, K, s);
+    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref == 3 && NS == 2 &&
+        (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
+        return launch256<NS, ACT, 2, 4, 2, true>(A, lda, B, bias, out, ldc, M, N, K, s);
+    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
         (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
-        return launch256<NS, ACT>(A, lda, B, bias, out, ldc, M, N, K, s);
+        return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1)>(A, lda, B, bias, out, ldc, M, N, K, s);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
@@ -434,6 +531,12 @@ int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, con
 }
 
 }  // namespace
+
+#ifdef E3D_STAMPS
+extern "C" int e3d_debug_read_stamps(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(e3d_stamps), sizeof(long long) * 2 * 32 * 8);
+}
+#endif
 
 extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kmajor, const float* B,
                                           int64_t ldb, int b_kmajor, const float* bias, float* out,

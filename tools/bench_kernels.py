@@ -82,6 +82,17 @@ def attn_pmc():
     torch.cuda.synchronize()
 
 
+def gemm_pmc():
+    """Few launches of the dominant GEMM shape (65536 x 768 x 768, default mode) for a rocprofv3 --pmc pass."""
+    M, N, K = 65536, 768, 768
+    a = torch.randn(M, K, device=DEV)
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV)
+    for _ in range(5):
+        ops.gemm(a, w, b)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "attn": bench_attn, "attn_pmc": attn_pmc}[what]()
+    {"gemm": bench_gemm, "attn": bench_attn, "attn_pmc": attn_pmc, "gemm_pmc": gemm_pmc}[what]()
