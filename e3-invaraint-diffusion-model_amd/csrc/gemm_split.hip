@@ -441,8 +441,171 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the interleaved-staging kernel (bf16x3, 256x256 tiles, M % 256 == 0): one
+// workgroup per CU walks tiles b, b + G, b + 2G, ... and the k-tile stream does not stop at a tile
+// boundary -- while the last two k-steps of a tile run, the first two k-tiles of the NEXT output
+// tile are loaded and staged, so a tile costs its k loop plus its output stores; the first-load
+// latency (~11k cycles per tile in the stamps) and the workgroup relaunch are paid once per CU.
+// Staging addresses are a wave-uniform tile base (SGPRs) plus a per-item 32-bit offset that is the
+// same for every tile.
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ W,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int64_t ldc, int N, int K,
+                                                                 int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NS = 2, T_BYTES = BT * ROW64, BUF_BYTES = 2 * NS * T_BYTES;
+    constexpr int NI = 8;   // float4 items per thread and k-tile: 0..3 from A, 4..7 from W
+    const int total = tiles_m * tiles_n, nk = K / BK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    unsigned goff[NI];   // element offset from the tile base
+    int dst[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = tid + 512 * (i & 3), r = f >> 3, kg = f & 7;
+        goff[i] = (unsigned)(r * (i < 4 ? (int)lda : K) + kg * 4);
+        dst[i] = (i < 4 ? 0 : NS * T_BYTES) + swz_off(r, kg >> 1) + (kg & 1) * 8;
+    }
+
+    // load cursor: the k-tile the next global loads fetch (wave-uniform)
+    int ld_tile = blockIdx.x, ld_k = 0;
+    const float* ld_a;
+    const float* ld_w;
+    auto cursor_bases = [&]() {
+        const int lid = xcd_remap(ld_tile, total);
+        ld_a = A + (int64_t)(lid / tiles_n) * BT * lda + ld_k * BK;
+        ld_w = W + (int64_t)(lid % tiles_n) * BT * K + ld_k * BK;
+    };
+    auto cursor_advance = [&]() {
+        if (ld_k + 1 < nk) {
+            ++ld_k;
+            ld_a += BK;
+            ld_w += BK;
+        } else if (ld_tile + (int)gridDim.x < total) {
+            ld_tile += gridDim.x;
+            ld_k = 0;
+            cursor_bases();
+        }   // else: stay on the stream's last k-tile (re-staged into a buffer nobody reads again)
+    };
+    f32x4 rg[NI];
+    auto item_load = [&](int i) { rg[i] = *reinterpret_cast<const f32x4*>((i < 4 ? ld_a : ld_w) + goff[i]); };
+    auto item_store = [&](int i, unsigned char* buf) {
+        bf16x4 p[NS];
+        split4<NS>(rg[i], p);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(buf + s * T_BYTES + dst[i]) = p[s];
+    };
+
+    cursor_bases();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) item_load(i);
+    cursor_advance();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) item_store(i, smem_raw);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) item_load(i);
+    cursor_advance();
+    __syncthreads();
+
+    int a_row[4], b_row[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_row[m] = wr * 128 + m * 32 + l31;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b_row[n] = wc * 64 + n * 32 + l31;
+    int cur = 0;
+
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char* base = smem_raw + cur * BUF_BYTES;
+            unsigned char* next = smem_raw + (cur ^ 1) * BUF_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[NS][4], fb[NS][2];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        fb[s][n] = *reinterpret_cast<const bf16x8*>(base + (NS + s) * T_BYTES +
+                                                                    swz_off(b_row[n], 2 * ks + half));
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int g = ks * 4 + m;   // MFMA group g stages item g: stream k-tile +1 out, +2 in
+                    item_store(g, next);
+                    item_load(g);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            cursor_advance();
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        const int lid = xcd_remap(tile, total);
+        const int row0 = (lid / tiles_n) * BT, col0 = (lid % tiles_n) * BT;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = col0 + wc * 64 + n * 32 + l31;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float* o = out + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[m][n][r] + bv;
+                    if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
+                    if (ACT == E3D_ACT_SILU) v = silu(v);
+                    o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int ACT>
+int launch256p(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
+               int K, hipStream_t s) {
+    const int tiles_m = M / BT, tiles_n = N / BT;
+    constexpr size_t lds = 2 * 2 * 2 * BT * ROW64;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        n_cu -= n_cu % 8;   // whole XCD rounds: tile t then runs on XCD t % 8, as the remap assumes
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256p_kernel<ACT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int total = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_split256p_kernel<ACT>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias,
+                       out, ldc, N, K, tiles_m, tiles_n);
+    return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
+}
+
 int g_tile_pref = -1;  // E3D_GEMM_TILE (experiments): 0 = 256x128 (8 waves of 64x64), 1 = 256x256 classic loop,
-                       // 2 = 256x128 two blocks per CU, 3 = 256x256 with interleaved staging (default)
+                       // 2 = 256x128 two blocks per CU, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
 
 template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE = false>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
@@ -466,11 +629,14 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
            int M, int N, int K, hipStream_t s) {
     if (g_tile_pref < 0) {
         const char* e = getenv("E3D_GEMM_TILE");
-        g_tile_pref = e ? atoi(e) : 3;
+        g_tile_pref = e ? atoi(e) : 4;
     }
     if (!A_KMAJ && !B_KMAJ && ldb == K && g_tile_pref == 2 && N % 128 == 0 && NS == 2)
         return launch256<NS, ACT, 2, 2, 1>(A, lda, B, bias, out, ldc, M, N, K, s);
-    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref == 3 && NS == 2 &&
+    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && NS == 2 && K >= 2 * BK &&
+        lda < (1 << 22) && (int64_t)(M / BT) * (N / BT) >= 256)
+        return launch256p<ACT>(A, lda, B, bias, out, ldc, M, N, K, s);
+    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 3 && NS == 2 &&
         (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
         return launch256<NS, ACT, 2, 4, 2, true>(A, lda, B, bias, out, ldc, M, N, K, s);
     if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
