@@ -340,6 +340,15 @@ extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q
     }
     E3D_REQUIRE((int64_t)B * nh * ((Lq + 31) / 32) < (1ll << 30), "attn_split: too many tiles");
     hipStream_t s = (hipStream_t)stream;
+    static int coop = -1;   // E3D_ATTN_COOP=0: per-wave kernel below for every shape (A/B experiments)
+    if (coop < 0) {
+        const char* e = getenv("E3D_ATTN_COOP");
+        coop = e ? atoi(e) : 1;
+    }
+    // two-wave groups (q_tiles % 4 != 0) measured slower than the per-wave kernel: too little sharing per barrier
+    if (terms == 3 && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1))
+        return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
+                                    Lq, Lk, g_skip_padded, s);
     if (terms == 3)
         return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
     return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);

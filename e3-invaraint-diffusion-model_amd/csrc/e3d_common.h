@@ -11,6 +11,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void e3d_set_error(const char* fmt, ...);
 
+// attn_relkey_coop.hip: workgroup-cooperative bf16x3 attention forward (internal; arguments validated by the caller)
+int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
+                         const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
+                         const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
+                         hipStream_t s);
+
 #define E3D_REQUIRE(cond, ...)       \
     do {                             \
         if (!(cond)) {               \
