@@ -139,8 +139,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # E3D_BENCH_REHEARSAL=1: the multi-rank control path on a ONE-GPU box (all ranks on cuda:0, gloo for the
+        # barrier / max-over-ranks) -- a plumbing check, never a measurement
+        rehearsal = os.environ.get("E3D_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -223,8 +230,8 @@ def main():
 
     modes = sorted(by_mode)
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip] + [by_mode[m] for m in modes], device=device,
-                         dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip] + [by_mode[m] for m in modes],
+                         device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, elapsed_cached, elapsed_skip, *rest = t.tolist()
         by_mode = dict(zip(modes, rest))
