@@ -129,6 +129,9 @@ def main():
                     choices=["f32", "bf16x3", "bf16x6"],
                     help="GEMM arithmetic of the headline value (see DESIGN.md section 3)")
     ap.add_argument("--only-default-mode", action="store_true", help="skip timing the other GEMM modes")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profile runs: only the headline loop (dense key sweep), no extras -- every attention "
+                         "launch in a rocprofv3 trace of this command is then the launch `roofline` describes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,11 +196,13 @@ def main():
         pkg.ops.set_gemm_mode(args.gemm_mode)
         pkg.ops.set_attn_mode(args.gemm_mode)
         lib.e3d_attn_skip_padded_tiles(1)
-        timed(full_step, 1)
-        elapsed_skip = timed(full_step, max(1, args.steps // 2)) / max(1, args.steps // 2)
+        elapsed_skip = float("nan")
+        if not args.headline_only:
+            timed(full_step, 1)
+            elapsed_skip = timed(full_step, max(1, args.steps // 2)) / max(1, args.steps // 2)
         lib.e3d_attn_skip_padded_tiles(0)
         # the other GEMM arithmetic modes, for transparency (same work, same kernels otherwise)
-        if not args.only_default_mode:
+        if not args.only_default_mode and not args.headline_only:
             for mode in pkg.ops.GEMM_MODES:
                 if mode != args.gemm_mode:
                     pkg.ops.set_gemm_mode(mode)
@@ -216,8 +221,10 @@ def main():
         def cached_step(i, x, out):
             return S._reverse_step(model, pk["ligand_attn_mask"], x, None, None, None, i, tab, None, cache, out, True)
 
-        timed(cached_step, 1)
-        elapsed_cached = timed(cached_step, args.steps)
+        elapsed_cached = float("nan")
+        if not args.headline_only:
+            timed(cached_step, 1)
+            elapsed_cached = timed(cached_step, args.steps)
 
         # per-launch durations of the named kernels (HIP events on the launch stream), one dense step
         lib.e3d_attn_skip_padded_tiles(0)
@@ -243,12 +250,24 @@ def main():
     attn_ms, n_attn = avg_ms("attn_relkey")
     gemm_ms = sum(a.elapsed_time(b) for n, a, b, _ in trace if n == "gemm")
     gemm_flops = sum(2.0 * m[0] * m[1] * m[2] for n, _, _, m in trace if n == "gemm")
+    by_shape = {}
+    for n, ev0, ev1, m in trace:
+        if n == "gemm":
+            by_shape.setdefault(tuple(int(v) for v in m[:3]), []).append(ev0.elapsed_time(ev1))
+    shapes = sorted(({"M": k[0], "N": k[1], "K": k[2], "launches_per_step": len(v), "avg_launch_ms": sum(v) / len(v),
+                      "TFLOPs": 2.0 * k[0] * k[1] * k[2] / (sum(v) / len(v) * 1e-3) / 1e12} for k, v in by_shape.items()),
+                    key=lambda d: -d["avg_launch_ms"] * d["launches_per_step"])
 
     if rank == 0:
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
-            traffic = json.load(open(tj)).get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
+            tdict = json.load(open(tj))
+            traffic = tdict.get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
+            top = shapes[0]
+            gemm_traffic = tdict.get(f"gemm_{top['M']}x{top['N']}x{top['K']}_hbm_bytes_per_launch")
+        else:
+            top, gemm_traffic = shapes[0], None
         a_tf = attn_flops(B, L) / (attn_ms * 1e-3) / 1e12
         gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.gemm_mode]
         a_gb = attn_bytes(B, L) / (attn_ms * 1e-3) / 1e9
@@ -269,15 +288,15 @@ def main():
                                    "12+12 layers x 768, T=1000 schedule, encoder recomputed every step (as the reference)",
                        "pockets_per_gpu": B, "seq_len": L, "parallelism": f"pocket-sharded x{world}, no collective"},
             "model_tflops": structure_flops_per_pocket(L) * B * world * args.steps / elapsed / 1e12,
-            "value_encoder_cached": B * world * args.steps / elapsed_cached,
-            "value_padding_skip": B * world / elapsed_skip,
+            "value_encoder_cached": None if args.headline_only else B * world * args.steps / elapsed_cached,
+            "value_padding_skip": None if args.headline_only else B * world / elapsed_skip,
             "value_notes": "value = dense attention sweep over all padded keys + encoder recomputed every step "
                            "(every flop the reference does); value_padding_skip = product default (key sweep stops "
                            "after the last valid key, bit-identical results); value_encoder_cached = the sampler's "
                            "real loop (pocket encoder + cross K/V once per batch), with the padding skip",
             # the binding roofline of the rel-key attention kernel: whichever of MFMA time (algorithmic flops /
             # peak) and HBM time (algorithmic bytes / 8 TB/s) is larger; frac = that time / measured time
-            "roofline": (lambda t_mfma, t_hbm: {
+            "roofline_attention": (lambda t_mfma, t_hbm: {
                 "kernel": ("attn_fwd_kernel<relkey> (e3d_relkey_attn_fwd)" if args.gemm_mode == "f32" else
                            f"attn_coop_kernel<8 waves, relkey> for bf16x3, attn_fwd_split_kernel / attn_fwd_kernel otherwise (e3d_relkey_attn_fwd_split, {args.gemm_mode})"),
                 "bound": "hbm" if t_hbm > t_mfma else "mfma",
@@ -290,6 +309,18 @@ def main():
                 "algorithmic_TFLOPs": a_tf, "mfma_frac": a_tf / gemm_peak,
                 "hbm_algorithmic_GBps": a_gb, "hbm_frac": a_gb / PEAK_HBM_GBPS})(
                     attn_flops(B, L) / (gemm_peak * 1e12) * 1e3, attn_bytes(B, L) / (PEAK_HBM_GBPS * 1e9) * 1e3),
+            # the dominant kernel (~2/3 of the step): the GEMM, priced on its most time-consuming shape.  flops per
+            # launch = 2MNK; peak = the dense bf16 MFMA rate / cross products per fp32 product
+            "roofline": {"kernel": ("gemm_split256p_kernel (e3d_gemm_bias_act_f32_split)" if args.gemm_mode == "bf16x3" else
+                                    f"GEMM kernel of mode {args.gemm_mode}") + f", M={top['M']} N={top['N']} K={top['K']}",
+                         "bound": "mfma", "achieved": top["TFLOPs"], "peak": gemm_peak, "unit": "TFLOP/s",
+                         "frac": top["TFLOPs"] / gemm_peak, "traffic": gemm_traffic,
+                         "avg_launch_ms": top["avg_launch_ms"], "launches_per_step": top["launches_per_step"],
+                         "algorithmic_bytes_per_launch": 4.0 * (top["M"] * top["K"] + top["N"] * top["K"] +
+                                                               top["M"] * top["N"] + top["N"]),
+                         "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes; "
+                                      "traffic = HBM bytes per launch from the PMC passes in profiles/traffic.json"},
+            "gemm_shapes": shapes,
             "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",
                               "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
                               "peak": gemm_peak, "unit": "TFLOP/s (algorithmic 2MNK)",

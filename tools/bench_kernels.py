@@ -83,8 +83,9 @@ def attn_pmc():
 
 
 def gemm_pmc():
-    """Few launches of the dominant GEMM shape (65536 x 768 x 768, default mode) for a rocprofv3 --pmc pass."""
-    M, N, K = 65536, 768, 768
+    """Few launches of the dominant GEMM shape (65536 x 2304 x 768: the packed QKV projection, default mode)
+    for a rocprofv3 --pmc pass; another N as the second argument."""
+    M, N, K = 65536, int(sys.argv[2]) if len(sys.argv) > 2 else 2304, 768
     a = torch.randn(M, K, device=DEV)
     w = torch.randn(N, K, device=DEV) / K ** 0.5
     b = torch.randn(N, device=DEV)
