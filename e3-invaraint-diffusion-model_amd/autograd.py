@@ -111,13 +111,15 @@ class _Attention(torch.autograd.Function):
         return q_src, kv_src[:, :H], kv_src[:, H:]
 
     @staticmethod
-    def forward(ctx, q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos):
+    def forward(ctx, q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p=0.0):
         H = nh * 64
         q, k, v = _Attention._views(q_src, kv_src, H)
+        drop = (float(drop_p), ops.next_dropout_seed()) if drop_p > 0 else (0.0, 0)
         out, lse = ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos,
-                                 want_lse=True)
+                                 want_lse=True, drop=drop)
         ctx.save_for_backward(q_src, kv_src, dist_emb, key_mask, out, lse)
         ctx.dims = (B, nh, Lq, Lk, max_pos)
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -134,13 +136,26 @@ class _Attention(torch.autograd.Function):
         lib = hip.lib()
         ws = torch.empty((lib.e3d_relkey_attn_bwd_workspace_floats(B, nh, Lq, Lk, int(dist_emb is not None)),),
                          device=q.device, dtype=torch.float32)
-        hip.check(lib.e3d_relkey_attn_bwd(
+        hip.check(lib.e3d_relkey_attn_bwd_drop(
             _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0), _p(v), Lk * v.stride(0),
             v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse), _p(dout),
             _p(dq), Lq * dq.stride(0), dq.stride(0), _p(dk), Lk * dk.stride(0), dk.stride(0),
-            _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, _stream()),
-            "e3d_relkey_attn_bwd")
-        return dq_src, dkv_src, dE, None, None, None, None, None, None
+            _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, ctx.drop[0], ctx.drop[1],
+            _stream()), "e3d_relkey_attn_bwd_drop")
+        return dq_src, dkv_src, dE, None, None, None, None, None, None, None
+
+
+class _Dropout(torch.autograd.Function):
+    """y = x * keep / (1 - p'); the gradient passes through the same decisions (regenerated from the seed)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        ctx.p, ctx.seed = float(p), ops.next_dropout_seed()
+        return ops.dropout(x.contiguous(), ctx.p, ctx.seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed), None
 
 
 class _ResidualLayerNorm(torch.autograd.Function):
@@ -228,12 +243,23 @@ class functional:
         return ops.gemm(x, weight, bias, act)
 
     @staticmethod
-    def attention(q_src, kv_src, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0):
-        """q_src = packed qkv [B*L,3H] (kv_src None, self-attention) or q [B*Lq,H] with packed kv [B*Lk,2H]."""
+    def attention(q_src, kv_src, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, drop_p=0.0):
+        """q_src = packed qkv [B*L,3H] (kv_src None, self-attention) or q [B*Lq,H] with packed kv [B*Lk,2H].
+        ``drop_p`` > 0 (training): dropout on the attention probabilities."""
         if _needs_grad(q_src, kv_src, dist_emb):
-            return _Attention.apply(q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos)
+            return _Attention.apply(q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p)
         q, k, v = _Attention._views(q_src, kv_src, nh * 64)
-        return ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos)
+        drop = (float(drop_p), ops.next_dropout_seed()) if drop_p > 0 else None
+        return ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos, drop=drop)
+
+    @staticmethod
+    def dropout(x, p, training=True):
+        """nn.Dropout(p) of the reference: identity unless ``training`` and p > 0."""
+        if not training or not p:
+            return x
+        if _needs_grad(x):
+            return _Dropout.apply(x, p)
+        return ops.dropout(x.contiguous(), p, ops.next_dropout_seed())
 
     @staticmethod
     def residual_layernorm(x, residual, gamma, beta, eps):

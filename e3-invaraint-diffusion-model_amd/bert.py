@@ -77,6 +77,7 @@ class BertAttention(nn.Module):
         self.output = BertSelfOutput(cfg)
         self.num_heads = cfg.num_attention_heads
         self.eps = cfg.layer_norm_eps
+        self.config = cfg
 
 
 class BertIntermediate(nn.Module):
@@ -142,23 +143,23 @@ def kv_weights(sa):
             _packed(sa, "b_kv", [sa.key.bias, sa.value.bias]))
 
 
-def warn_dropout_once(module, p):
-    """The HIP path has no dropout kernels yet: training runs with dropout disabled (the
-    reference trains with p = 0.1, structure_model/train_model.py:25).  Warn once per module."""
-    if module.training and p and not module.__dict__.get("_e3d_warned"):
-        import warnings
-        warnings.warn(f"dropout p={p} requested in training mode: the HIP kernels apply no dropout "
-                      "(DESIGN.md section 8)", stacklevel=3)
-        module.__dict__["_e3d_warned"] = True
+def dropout_rates(module):
+    """(hidden_dropout_prob, attention_probs_dropout_prob) in training mode, (0, 0) in eval -- where
+    transformers 4.38.2 applies ``nn.Dropout``: after the self/cross-attention softmax, after
+    ``BertSelfOutput.dense`` and after ``BertOutput.dense``."""
+    if not module.training:
+        return 0.0, 0.0
+    cfg = module.config
+    return float(getattr(cfg, "hidden_dropout_prob", 0.0)), float(getattr(cfg, "attention_probs_dropout_prob", 0.0))
 
 
 # ----------------------------------------------------------------------------- executors
-def _attention_output(att, ctx, x):
-    o = F.linear(ctx, att.output.dense.weight, att.output.dense.bias)
+def _attention_output(att, ctx, x, p_hidden=0.0):
+    o = F.dropout(F.linear(ctx, att.output.dense.weight, att.output.dense.bias), p_hidden)
     return F.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
 
 
-def run_self_attention(att, x, mask, B, L):
+def run_self_attention(att, x, mask, B, L, drop=(0.0, 0.0)):
     """BertAttention on x [B*L,H] with key padding mask [B,L] (1/0): fused QKV GEMM ->
     fused relative-key attention -> out-proj GEMM -> residual + LayerNorm."""
     sa = att.self
@@ -167,8 +168,8 @@ def run_self_attention(att, x, mask, B, L):
     relkey = sa.position_embedding_type == "relative_key"
     ctx = F.attention(qkv, None, B, att.num_heads, L, L, key_mask=mask,
                       dist_emb=sa.distance_embedding.weight if relkey else None,
-                      max_pos=sa.max_position_embeddings)
-    return _attention_output(att, ctx, x)
+                      max_pos=sa.max_position_embeddings, drop_p=drop[1])
+    return _attention_output(att, ctx, x, drop[0])
 
 
 def project_cross_kv(att, enc):
@@ -178,30 +179,31 @@ def project_cross_kv(att, enc):
     return F.linear(enc, w, b)
 
 
-def run_cross_attention(att, x, kv, enc_mask, B, Lq, Lk):
+def run_cross_attention(att, x, kv, enc_mask, B, Lq, Lk, drop=(0.0, 0.0)):
     q = F.linear(x, att.self.query.weight, att.self.query.bias)
-    ctx = F.attention(q, kv, B, att.num_heads, Lq, Lk, key_mask=enc_mask)
-    return _attention_output(att, ctx, x)
+    ctx = F.attention(q, kv, B, att.num_heads, Lq, Lk, key_mask=enc_mask, drop_p=drop[1])
+    return _attention_output(att, ctx, x, drop[0])
 
 
-def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None):
-    x = run_self_attention(layer.attention, x, mask, B, L)
+def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None, drop=(0.0, 0.0)):
+    """``drop`` = (hidden, attention-probability) dropout rates of this call (training only)."""
+    x = run_self_attention(layer.attention, x, mask, B, L, drop)
     if hasattr(layer, "crossattention"):
         if cross_kv is None:
             raise ValueError("decoder layer needs encoder states")
-        x = run_cross_attention(layer.crossattention, x, cross_kv, enc_mask, B, L, Lk)
+        x = run_cross_attention(layer.crossattention, x, cross_kv, enc_mask, B, L, Lk, drop)
     inter = F.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
-    o = F.linear(inter, layer.output.dense.weight, layer.output.dense.bias)
+    o = F.dropout(F.linear(inter, layer.output.dense.weight, layer.output.dense.bias), drop[0])
     return F.residual_layernorm(o, x, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps)
 
 
 def run_encoder(encoder, x, mask, B, L, enc=None, enc_mask=None, Lk=None, cross_kv=None):
     """BertEncoder(...).last_hidden_state on flat activations.  ``cross_kv`` (list, one per
     layer) short-cuts the per-layer K/V projection of ``enc``."""
-    warn_dropout_once(encoder, getattr(encoder.config, "hidden_dropout_prob", 0.0))
+    drop = dropout_rates(encoder)
     for i, layer in enumerate(encoder.layer):
         kv = None
         if hasattr(layer, "crossattention"):
             kv = cross_kv[i] if cross_kv is not None else project_cross_kv(layer.crossattention, enc)
-        x = run_layer(layer, x, mask, B, L, kv, enc_mask, Lk)
+        x = run_layer(layer, x, mask, B, L, kv, enc_mask, Lk, drop)
     return x

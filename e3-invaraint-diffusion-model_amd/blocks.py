@@ -34,10 +34,11 @@ class SELayer(nn.Module):
         assert rows_per_cond in (1, L), (x.shape, c.shape)
         m0, m2 = self.adaLN_modulation[0], self.adaLN_modulation[2]
         mod = F.linear(F.linear(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
-        att = bert.run_self_attention(self.attn, x, mask, B, L)
+        drop = bert.dropout_rates(self.attn)   # (hidden, attention) rates in training, zeros in eval
+        att = bert.run_self_attention(self.attn, x, mask, B, L, drop)
         x = F.adaln_gate(x, att, mod, 0, rows_per_cond)
-        h = F.linear(x, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_GELU)
-        h = F.linear(h, self.mlp[3].weight, self.mlp[3].bias)
+        h = F.dropout(F.linear(x, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_GELU), self.mlp[2].p, self.training)
+        h = F.dropout(F.linear(h, self.mlp[3].weight, self.mlp[3].bias), self.mlp[4].p, self.training)
         return F.adaln_gate(x, h, mod, 1, rows_per_cond)
 
 
@@ -62,7 +63,7 @@ class GaussianFourierProjection(nn.Module):
 
 
 class BertEmbeddings(nn.Module):
-    """Linear -> LayerNorm -> dropout(eval: identity) (structure_model/model.py:100-118)."""
+    """Linear -> LayerNorm -> dropout (structure_model/model.py:100-118)."""
 
     def __init__(self, in_features, bert_config):
         super().__init__()
@@ -71,6 +72,15 @@ class BertEmbeddings(nn.Module):
         self.dropout = nn.Dropout(bert_config.hidden_dropout_prob)
 
     def run(self, x2d, post_add=None, rows_per_add=1):
+        """``post_add`` [M / rows_per_add, H] is what the caller adds to the embedding afterwards (the sequence
+        model's timestep term): fused into the kernel, except in training with dropout, which sits between."""
+        if self.training and self.dropout.p > 0:
+            e = F.embed_layernorm(x2d, self.linear.weight, self.linear.bias, self.LayerNorm.weight,
+                                  self.LayerNorm.bias, self.LayerNorm.eps, None, 1)
+            e = F.dropout(e, self.dropout.p)
+            if post_add is not None:
+                e = (e.view(-1, rows_per_add, e.shape[1]) + post_add[:, None, :]).view_as(e)
+            return e
         return F.embed_layernorm(x2d, self.linear.weight, self.linear.bias, self.LayerNorm.weight,
                                    self.LayerNorm.bias, self.LayerNorm.eps, post_add, rows_per_add)
 

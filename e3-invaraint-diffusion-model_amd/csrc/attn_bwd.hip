@@ -68,13 +68,14 @@ __device__ __forceinline__ void store_rows64(const f32x16& o0, const f32x16& o1,
     }
 }
 
-template <bool RELKEY>
+template <bool RELKEY, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs, int64_t k_rs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb, int P,
     const float* __restrict__ key_mask, const float* __restrict__ dout, const float* __restrict__ outp,
     const float* __restrict__ lse, float* __restrict__ dq, int64_t dq_bs, int64_t dq_rs, float* __restrict__ Pm,
-    float* __restrict__ dSm, float* __restrict__ dE_part, int nh, int Lq, int Lk, int q_tiles, int n_units) {
+    float* __restrict__ dSm, float* __restrict__ dE_part, int nh, int Lq, int Lk, int q_tiles, int n_units,
+    E3dDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qi = lane & 31, half = lane >> 5;
@@ -170,8 +171,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
             load_frag8(vf, vb + (int64_t)min(r0 + qi, Lk - 1) * v_rs, half);
             ds = mfma_tile(vf, dof);
         }
+        if (DROP) {
+            // forward: O = (P o m) V with m in {0, 1/(1-p)}  =>  dP = (V dO^T) o m, dS = P (dP - delta) / 8 with
+            // delta = rowsum(dO o O) unchanged; launch B needs P o m (dV = (P o m)^T dO), materialised below
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = s[r] * (ds[r] - delta) * 0.125f;
+            for (int g = 0; g < 4; ++g) {
+                float m[4];
+                e3d_drop_mult4(drop, e3d_attn_drop_idx4(bh, Lq, Lk, q0 + qi, r0 + 8 * g + 4 * half), m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ds[4 * g + j] = s[4 * g + j] * (ds[4 * g + j] * m[j] - delta) * 0.125f;
+                    s[4 * g + j] *= m[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = s[r] * (ds[r] - delta) * 0.125f;
+        }
 
         // materialise P and dS (query-major) through the LDS transpose buffer
         wave_lds_sync();  // previous tile's readers of X are done
@@ -318,12 +334,15 @@ extern "C" int64_t e3d_relkey_attn_bwd_workspace_floats(int B, int nh, int Lq, i
     return 2 * pm + part;
 }
 
-extern "C" int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
-                                   int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
-                                   const float* key_mask, const float* out, const float* lse, const float* dout,
-                                   float* dq, int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs,
-                                   float* dv, int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, float* workspace, int B,
-                                   int nh, int Lq, int Lk, void* stream) {
+extern "C" int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                        int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb,
+                                        int P, const float* key_mask, const float* out, const float* lse,
+                                        const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs, float* dk,
+                                        int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs, int64_t dv_rs,
+                                        float* d_dist_emb, float* workspace, int B, int nh, int Lq, int Lk, float drop_p,
+                                        uint64_t drop_seed, void* stream) {
+    E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_bwd: drop_p=%g outside [0, 1)", (double)drop_p);
+    const E3dDrop drop = e3d_drop_make(drop_p, drop_seed);
     E3D_REQUIRE(q && k && v && out && lse && dout && dq && dk && dv && workspace, "attn_bwd: null pointer");
     E3D_REQUIRE(B > 0 && nh > 0 && Lq > 0 && Lk > 0, "attn_bwd: bad shape");
     E3D_REQUIRE(q_rs % 4 == 0 && k_rs % 4 == 0 && v_rs % 4 == 0 && dq_rs % 4 == 0 && dk_rs % 4 == 0 && dv_rs % 4 == 0 &&
@@ -343,14 +362,18 @@ extern "C" int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, c
         const int n_units = B * nh * q_tiles;
         const int n_blocks = (n_units + wpb - 1) / wpb;
         const size_t lds = (size_t)wpb * WAVE_LDS_F * sizeof(float);
-        if (dist_emb)
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k, k_bs, k_rs,
-                               v, v_bs, v_rs, dist_emb, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, Pm, dSm, part, nh, Lq,
-                               Lk, q_tiles, n_units);
-        else
-            hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k, k_bs,
-                               k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, Pm, dSm, part, nh,
-                               Lq, Lk, q_tiles, n_units);
+#define E3D_BWD_DQ(RK, DR)                                                                                              \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<RK, DR>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k, k_bs, k_rs, v, \
+                       v_bs, v_rs, dist_emb, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, Pm, dSm, part, nh, Lq, Lk,      \
+                       q_tiles, n_units, drop)
+        if (dist_emb) {
+            if (drop_p > 0.f) E3D_BWD_DQ(true, true);
+            else E3D_BWD_DQ(true, false);
+        } else {
+            if (drop_p > 0.f) E3D_BWD_DQ(false, true);
+            else E3D_BWD_DQ(false, false);
+        }
+#undef E3D_BWD_DQ
         int rc = e3d_launch_status("e3d_relkey_attn_bwd (dq)");
         if (rc) return rc;
     }
@@ -370,4 +393,15 @@ extern "C" int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, c
         return e3d_launch_status("e3d_relkey_attn_bwd (dE)");
     }
     return 0;
+}
+
+extern "C" int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                   int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
+                                   const float* key_mask, const float* out, const float* lse, const float* dout,
+                                   float* dq, int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs,
+                                   float* dv, int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, float* workspace, int B,
+                                   int nh, int Lq, int Lk, void* stream) {
+    return e3d_relkey_attn_bwd_drop(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout, dq,
+                                    dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, d_dist_emb, workspace, B, nh, Lq, Lk,
+                                    0.f, 0, stream);
 }

@@ -139,12 +139,12 @@ __device__ __forceinline__ f32x16 dot_tile(const bf16x8 (&x)[4][NS], const bf16x
     return acc;
 }
 
-template <int NS, bool RELKEY>
+template <int NS, bool RELKEY, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq,
-    int Lk, int q_tiles, int n_units, int skip_padded_tiles) {
+    int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qi = lane & 31, half = lane >> 5;
@@ -255,6 +255,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        if (DROP) {   // dropout on the probabilities: the row sum above stays un-dropped (softmax first, then dropout)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m[4];
+                e3d_drop_mult4(drop, e3d_attn_drop_idx4(bh, Lq, Lk, q0 + qi, r0 + 8 * g + 4 * half), m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] *= m[j];
+            }
+        }
 
         // O^T += V^T P^T, two 16-key steps; P^T registers 8st..8st+7 are the B operand
 #pragma unroll
@@ -295,21 +304,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
 
 int g_skip_padded = 1;
 
-template <int NS>
+template <int NS, bool DROP = false>
 int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
            int64_t v_bs, int64_t v_rs, const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
-           int B, int nh, int Lq, int Lk, hipStream_t s) {
+           int B, int nh, int Lq, int Lk, hipStream_t s, E3dDrop drop = E3dDrop{0, 0, 1.f}) {
     const int q_tiles = (Lq + 31) / 32;
     const int n_units = B * nh * q_tiles;
     const int wpb = 4;
     const int n_blocks = (n_units + wpb - 1) / wpb;
     const size_t lds = (size_t)wpb * WAVE_LDS_F * sizeof(float);
     if (dist_emb)
-        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded);
+        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true, DROP>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
     else
-        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded);
+        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false, DROP>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
     return e3d_launch_status("e3d_relkey_attn_fwd_split");
 }
 
@@ -321,10 +330,12 @@ extern "C" int e3d_attn_skip_padded_tiles(int enable) {
     return prev;
 }
 
-extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
-                                         int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
-                                         const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
-                                         int B, int nh, int Lq, int Lk, int terms, void* stream) {
+extern "C" int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                              int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                                              const float* dist_emb, int P, const float* key_mask, float* out,
+                                              float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
+                                              uint64_t drop_seed, void* stream) {
+    E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_split: drop_p=%g outside [0, 1)", (double)drop_p);
     E3D_REQUIRE(q && k && v && out, "attn_split: null pointer");
     E3D_REQUIRE(B > 0 && nh > 0 && Lq > 0 && Lk > 0, "attn_split: bad shape B=%d nh=%d Lq=%d Lk=%d", B, nh, Lq, Lk);
     E3D_REQUIRE(q_rs % 4 == 0 && k_rs % 4 == 0 && v_rs % 2 == 0 && q_bs % 4 == 0 && k_bs % 4 == 0 && v_bs % 2 == 0,
@@ -340,6 +351,12 @@ extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q
     }
     E3D_REQUIRE((int64_t)B * nh * ((Lq + 31) / 32) < (1ll << 30), "attn_split: too many tiles");
     hipStream_t s = (hipStream_t)stream;
+    if (drop_p > 0.f) {   // training with attention-probability dropout: per-wave kernel
+        const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
+        if (terms == 3)
+            return launch<2, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s, d);
+        return launch<3, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s, d);
+    }
     static int coop = -1;   // E3D_ATTN_COOP=0: per-wave kernel below for every shape (A/B experiments)
     if (coop < 0) {
         const char* e = getenv("E3D_ATTN_COOP");
@@ -352,4 +369,12 @@ extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q
     if (terms == 3)
         return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
     return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
+}
+
+extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                         int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                                         const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
+                                         int B, int nh, int Lq, int Lk, int terms, void* stream) {
+    return e3d_relkey_attn_fwd_split_drop(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B,
+                                          nh, Lq, Lk, terms, 0.f, 0, stream);
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <math.h>
 
 #include "../../include/e3d_hip.h"
 
@@ -50,6 +51,38 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// ---------------------------------------------------------------- dropout decisions
+// Counter-based: one splitmix64 hash per group of 4 consecutive elements, one 16-bit field per
+// element; an element is KEPT iff its field >= thr, kept values are scaled by 65536 / (65536 - thr)
+// (the exact inverse keep probability of this generator, so the op is unbiased).  Forward and
+// backward kernels regenerate the same decisions from (seed, element index): no mask is stored.
+struct E3dDrop {
+    uint64_t seed;
+    uint32_t thr;
+    float scale;
+};
+static inline E3dDrop e3d_drop_make(float p, uint64_t seed) {
+    E3dDrop d;
+    long t = lrintf(p * 65536.0f);
+    t = t < 0 ? 0 : (t > 65535 ? 65535 : t);
+    d.seed = seed;
+    d.thr = (uint32_t)t;
+    d.scale = 65536.0f / (float)(65536 - t);
+    return d;
+}
+__device__ __forceinline__ void e3d_drop_mult4(const E3dDrop d, uint64_t idx4, float (&m)[4]) {
+    uint64_t z = idx4 + d.seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = ((uint32_t)(z >> (16 * j)) & 0xFFFFu) >= d.thr ? d.scale : 0.f;
+}
+// attention probabilities P[b, h, q, key]: group index of keys key0 .. key0+3 (key0 % 4 == 0)
+__device__ __forceinline__ uint64_t e3d_attn_drop_idx4(int bh, int Lq, int Lk, int q, int key0) {
+    return ((uint64_t)bh * Lq + q) * (uint64_t)((Lk + 3) >> 2) + (uint64_t)(key0 >> 2);
 }
 
 // XCD-aware remap (cdna_hip_programming.md T1, bijective form): consecutive logical ids

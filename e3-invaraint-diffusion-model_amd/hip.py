@@ -6,7 +6,7 @@ The library is the product's only compute path: there is no CPU or eager-PyTorch
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3D_HIP_LIB", os.path.join(_HERE, "libe3d_hip.so"))   # override: kernel experiments
@@ -34,6 +34,14 @@ _SIGNATURES = {
     "e3d_relkey_attn_bwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
                                     _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                     _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "e3d_dropout_f32": (c_int, [_P, c_float, c_uint64, _P, c_int64, _P]),
+    "e3d_relkey_attn_fwd_split_drop": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                               _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float,
+                                               c_uint64, _P]),
+    "e3d_relkey_attn_bwd_drop": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
+                                         _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                         _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint64, _P]),
+    "e3d_attn_dropout_mask": (c_int, [c_int, c_int, c_int, c_int, c_float, c_uint64, _P, _P]),
     "e3d_layernorm_bwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "e3d_adaln_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P]),
     "e3d_act_fwd": (c_int, [_P, c_int, _P, c_int64, _P]),

@@ -99,9 +99,34 @@ def set_attn_mode(mode):
     return prev
 
 
-def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False, mode=None):
+def next_dropout_seed():
+    """A fresh 63-bit seed for one dropout site call, drawn from torch's global CPU generator
+    (so ``torch.manual_seed`` makes training runs repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (), dtype=torch.int64))
+
+
+def dropout(x, p, seed, out=None):
+    """out = x * keep / (1 - p'): the counter-based dropout of include/e3d_hip.h.  The backward pass is the
+    same call on the gradient with the same (p, seed)."""
+    _chk(x, "dropout.x")
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    hip.check(hip.lib().e3d_dropout_f32(_p(x), float(p), int(seed), _p(out), x.numel(), _stream()), "e3d_dropout_f32")
+    return out
+
+
+def attn_dropout_mask(B, nh, Lq, Lk, p, seed, device="cuda"):
+    """Test aid: multipliers applied to the attention probabilities by ``attention(..., drop=(p, seed))``."""
+    out = torch.empty((B, nh, Lq, Lk), device=device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_attn_dropout_mask(B, nh, Lq, Lk, float(p), int(seed), _p(out), _stream()),
+              "e3d_attn_dropout_mask")
+    return out
+
+
+def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False, mode=None, drop=None):
     """q [B*Lq, >=nh*64] / k, v [B*Lk, ...] row-strided 2-D views (e.g. slices of a fused QKV
-    buffer).  Returns ctx [B*Lq, nh*64] (and lse [B,nh,Lq])."""
+    buffer).  Returns ctx [B*Lq, nh*64] (and lse [B,nh,Lq]).  ``drop`` = (p, seed): dropout on the
+    normalised probabilities (training); the exact-fp32 mode then runs its fp32-grade bf16x6 twin."""
     for n, t in (("q", q), ("k", k), ("v", v), ("key_mask", key_mask), ("dist_emb", dist_emb)):
         _chk(t, "attention." + n)
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
@@ -117,7 +142,10 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         args = (_p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
                 _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
                 B, nh, Lq, Lk)
-        if terms == 0:
+        if drop is not None and drop[0] > 0:
+            hip.check(hip.lib().e3d_relkey_attn_fwd_split_drop(*args, terms or 6, float(drop[0]), int(drop[1]), _stream()),
+                      "e3d_relkey_attn_fwd_split_drop")
+        elif terms == 0:
             hip.check(hip.lib().e3d_relkey_attn_fwd(*args, _stream()), "e3d_relkey_attn_fwd")
         else:
             hip.check(hip.lib().e3d_relkey_attn_fwd_split(*args, terms, _stream()), "e3d_relkey_attn_fwd_split")

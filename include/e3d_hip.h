@@ -178,6 +178,33 @@ int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, const float*
                         int64_t dv_rs, float* d_dist_emb, float* workspace, int B, int nh, int Lq,
                         int Lk, void* stream);
 
+/* ---- dropout (training): reference nn.Dropout(hidden_dropout_prob) in BertEmbeddings
+ * (structure_model/model.py:109-117), the SELayer MLP (model.py:45-47), BertSelfOutput / BertOutput and
+ * attention_probs_dropout_prob inside BertSelfAttention (transformers 4.38.2).  Decisions are a pure
+ * function of (seed, element index): 16-bit fields of a splitmix64 hash, keep iff field >= round(p*65536),
+ * kept values scaled by 65536 / (65536 - round(p*65536)).  The backward pass applies the same call to the
+ * gradient; nothing is stored. */
+int e3d_dropout_f32(const float* x, float p, uint64_t seed, float* out, int64_t n, void* stream);
+
+/* e3d_relkey_attn_fwd_split with dropout on the normalised probabilities (drop_p == 0: identical to it). */
+int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                   int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                                   const float* dist_emb, int P, const float* key_mask, float* out,
+                                   float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
+                                   uint64_t drop_seed, void* stream);
+
+/* e3d_relkey_attn_bwd for a forward that used (drop_p, drop_seed). */
+int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                             int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                             const float* dist_emb, int P, const float* key_mask, const float* out,
+                             const float* lse, const float* dout, float* dq, int64_t dq_bs,
+                             int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs, float* dv,
+                             int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, float* workspace, int B,
+                             int nh, int Lq, int Lk, float drop_p, uint64_t drop_seed, void* stream);
+
+/* Test aid: the multipliers (0 or 1/(1-p')) the two calls above apply to P[b,h,q,key] -> out [B,nh,Lq,Lk]. */
+int e3d_attn_dropout_mask(int B, int nh, int Lq, int Lk, float p, uint64_t seed, float* out, void* stream);
+
 /* LayerNorm backward on the saved pre-norm rows s [M,H]: ds = dLN/ds, dgamma/dbeta (overwritten;
  * gamma == NULL: no affine, as SELayer.norm1/norm2). */
 int e3d_layernorm_bwd(const float* dy, const float* s, const float* gamma, float eps, float* ds,

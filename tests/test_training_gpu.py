@@ -24,11 +24,12 @@ SMALL = dict(hidden_size=256, num_heads=4, intermediate_size=512, num_hidden_lay
              batch_size=8, max_epochs=6, min_epochs=1, dropout_p=0.0, lr=2e-3, lr_scheduler=None, pocket_ext=1)
 
 
-def test_structure_train_model_runs_and_learns(pkg, hip, tmp_path, monkeypatch):
+@pytest.mark.parametrize("dropout_p", [0.0, 0.1])   # 0.1 = the reference's training value (train_model.py:24)
+def test_structure_train_model_runs_and_learns(pkg, hip, tmp_path, monkeypatch, dropout_p):
     from e3diff_amd.structure_model import train_model as T
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(T, "NUM_THREAD", 0)
-    monkeypatch.setattr(T, "CONFIG", dict(T.CONFIG, **SMALL, timesteps=100))
+    monkeypatch.setattr(T, "CONFIG", dict(T.CONFIG, **dict(SMALL, dropout_p=dropout_p), timesteps=100))
     torch.manual_seed(0)
     train_dl, val_dl = T.get_dataloader(None, records=_records())
     enc, dec = T.build_configs()
@@ -47,7 +48,7 @@ def test_sequence_train_model_runs_and_learns(pkg, hip, tmp_path, monkeypatch):
     from e3diff_amd.sequence_model import train_model as T
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(T, "NUM_THREAD", 0)
-    monkeypatch.setattr(T, "CONFIG", dict(T.CONFIG, **SMALL, timesteps=50))
+    monkeypatch.setattr(T, "CONFIG", dict(T.CONFIG, **dict(SMALL, dropout_p=0.1), timesteps=50))
     torch.manual_seed(0)
     train_dl, val_dl = T.get_dataloader(None, records=_records())
     enc, dec = T.build_configs()

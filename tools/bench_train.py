@@ -29,12 +29,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
     args = ap.parse_args()
     L = args.seq_len
     layers = 12 if args.model == "structure" else 6
     B = args.batch or (32 if args.model == "structure" else 64)
     c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=layers,
-             max_position_embeddings=L, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+             max_position_embeddings=L, hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
     enc, dec = BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True)
     torch.manual_seed(0)
     if args.model == "structure":
@@ -74,7 +75,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     nparam = sum(p.numel() for p in params)
-    print(f"{args.model} training step: B={B} L={L} layers={layers} params={nparam / 1e6:.1f}M gemm_mode={pkg.ops.GEMM_MODE}: "
+    print(f"{args.model} training step: B={B} L={L} layers={layers} params={nparam / 1e6:.1f}M gemm_mode={pkg.ops.GEMM_MODE} dropout={args.dropout}: "
           f"{dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s (loss {float(loss.detach()):.4f}, peak mem "
           f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
 
