@@ -347,23 +347,26 @@ int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         hipStream_t s) {
+                         void* e_scratch, hipStream_t s) {
     const int q_tiles = (Lq + 31) / 32;
     const int W = q_tiles % 8 == 0 ? 8 : (q_tiles % 4 == 0 ? 4 : (q_tiles % 2 == 0 ? 2 : 1));
     if (!dist_emb)
         return launch_any<false>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, nullptr, P, key_mask, out, lse,
                                  B, nh, Lq, Lk, q_tiles, skip, s);
     // distance table -> bf16 hi/lo planes (stream-ordered scratch: (2P-1) x 64 x 2 planes)
+    // -- into the caller's scratch (same byte size as dist_emb) or, without one, a stream-ordered allocation
     const int n = (2 * P - 1) * D;
-    __bf16* planes = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)2 * n * sizeof(__bf16), s);
-    if (e != hipSuccess) {
-        e3d_set_error("attn_coop: hipMallocAsync of the distance-table planes failed: %s", hipGetErrorString(e));
-        return (int)e;
+    __bf16* planes = reinterpret_cast<__bf16*>(e_scratch);
+    if (!planes) {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)2 * n * sizeof(__bf16), s);
+        if (e != hipSuccess) {
+            e3d_set_error("attn_coop: hipMallocAsync of the distance-table planes failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
     }
     hipLaunchKernelGGL(split_planes_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dist_emb, planes, planes + n, n);
     const int rc = launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, planes + n, P, key_mask, out,
                                     lse, B, nh, Lq, Lk, q_tiles, skip, s);
-    (void)hipFreeAsync(planes, s);
+    if (!e_scratch) (void)hipFreeAsync(planes, s);
     return rc;
 }

@@ -16,7 +16,7 @@ void e3d_set_error(const char* fmt, ...);
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         hipStream_t s);
+                         void* e_scratch, hipStream_t s);
 
 #define E3D_REQUIRE(cond, ...)       \
     do {                             \

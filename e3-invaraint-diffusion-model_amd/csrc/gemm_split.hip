@@ -9,8 +9,8 @@
 //
 // Workgroup tile 256x128x32, 8 waves as 4(M) x 2(N), each wave 2x2 MFMA tiles of 32x32 (64
 // accumulator registers).  Staging: global loads (fp32) -> split in registers -> ds_write_b64
-// into per-term bf16 images [rows][32 + 8 pad] (80-byte rows: the ds_read_b128 fragment reads
-// of 16 lanes hit 16 distinct 4-bank slots), double buffered for TERMS = 3.
+// into per-term bf16 images of unpadded 64-byte rows whose 16-byte k-chunks are XOR-swizzled by the
+// row quad (conflict-free ds_read_b128 fragment reads), double buffered for TERMS = 3.
 //
 // Operand layouts (the three GEMMs of a Linear layer share one kernel):
 //     forward   y  = x W^T : A = x  [M,K] K-contiguous,  B = W [N,K] K-contiguous
@@ -25,8 +25,11 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BN = 128, BK = 32;
-constexpr int ROW_B = 80;  // bytes per LDS row: 32 bf16 + 16 B pad
+constexpr int BN = 128, BK = 32;
+// LDS rows are 64 bytes (32 bf16) unpadded, with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3: the 16 lanes
+// of a ds_read_b128 group (4 row quads) then hit 16 distinct 4-bank slots.
+constexpr int ROW_B = 64;
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW_B + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 template <int NS>
 __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&parts)[NS]) {
@@ -43,9 +46,9 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&parts)[NS]) {
 }
 
 // One operand's staging: NV float4-equivalents (4 consecutive k of one row) per thread.
-template <int ROWS, bool KMAJ>
+template <int ROWS, bool KMAJ, int NT = 512>
 struct Stager {
-    static constexpr int NV = ROWS * 8 / 512;  // items per thread (A: 4, B: 2)
+    static constexpr int NV = ROWS * 8 / NT;   // items per thread (512 threads: A 4, B 2)
     const float* src[NV];
     int off[NV];
     int64_t ld;
@@ -55,7 +58,7 @@ struct Stager {
         ld = ld_;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int f = tid + 512 * i;
+            const int f = tid + NT * i;
             int r, kg;
             if (KMAJ) { r = f % ROWS; kg = f / ROWS; }   // lanes along rows: coalesced k-rows
             else { r = f >> 3; kg = f & 7; }             // lanes along k: 128-byte row segments
@@ -63,7 +66,7 @@ struct Stager {
             gr = gr < row_limit ? gr : row_limit - 1;    // clamp: rows past the edge are discarded later
             src[i] = KMAJ ? base + gr : base + (int64_t)gr * ld + kg * 4;
             kbase[i] = kg * 4;
-            off[i] = r * ROW_B + kg * 8;
+            off[i] = swz_off(r, kg >> 1) + (kg & 1) * 8;
         }
     }
     __device__ __forceinline__ void load(f32x4 (&v)[NV], int k0, int K) const {
@@ -80,6 +83,24 @@ struct Stager {
             }
         }
     }
+    __device__ __forceinline__ void load_item(int i, f32x4& v, int k0, int K) const {
+        if (KMAJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kbase[i] + j;
+                v[j] = k < K ? src[i][(int64_t)k * ld] : 0.f;
+            }
+        } else {
+            v = *reinterpret_cast<const f32x4*>(src[i] + k0);
+        }
+    }
+    template <int NS>
+    __device__ __forceinline__ void store_item(int i, const f32x4& v, unsigned char* img, int part_bytes) const {
+        bf16x4 p[NS];
+        split4<NS>(v, p);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(img + s * part_bytes + off[i]) = p[s];
+    }
     template <int NS>
     __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes) const {
 #pragma unroll
@@ -92,8 +113,10 @@ struct Stager {
     }
 };
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
-__global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
+// WM = waves along M: 4 -> 256x128 tile, 512 threads; 2 -> 128x128 tile, 256 threads (used for grids of a few
+// tiles only: it halves the padded rows of an M = 64 problem; at M = 4096 it measured 25 % slower than WM = 4).
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+__global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M,
@@ -101,6 +124,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
                                                          int k_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NBUF = NS == 2 ? 2 : 1;
+    constexpr int BM = WM * 64, NT = WM * 128;
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
     constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
 
@@ -117,8 +141,8 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
     const int wr = wid >> 1, wc = wid & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    Stager<BM, A_KMAJ> sa;
-    Stager<BN, B_KMAJ> sb;
+    Stager<BM, A_KMAJ, NT> sa;
+    Stager<BN, B_KMAJ, NT> sb;
     sa.init(A, lda, row0, M, tid);
     sb.init(Bm, ldb, col0, N, tid);
 
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    f32x4 ra[Stager<BM, A_KMAJ>::NV], rb[Stager<BN, B_KMAJ>::NV];
+    f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
     sa.load(ra, k_begin, K);
     sb.load(rb, k_begin, K);
     sa.template store<NS>(ra, smem_raw, A_BYTES);
@@ -138,17 +162,28 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
     __syncthreads();
 
     const int nk = (K - k_begin + BK - 1) / BK;
-    const int a_frag = (wr * 64 + l31) * ROW_B + half * 16;
-    const int b_frag = (wc * 64 + l31) * ROW_B + half * 16;
+    const int a_row = wr * 64 + l31, b_row = wc * 64 + l31;   // fragment rows of m / n tile 0 (tile 1: +32)
     int cur = 0;
+    // Two buffers: interleaved staging as in the 256x256 kernel below -- each of the 4 MFMA groups of a k-step is
+    // preceded by its share of the staging of tile t+1 (split + ds_write of a register item, then the re-issue of
+    // that item's global load for tile t+2; the last steps re-stage the last tile into the buffer nobody reads).
+    constexpr bool PIPE = NBUF == 2;
+    constexpr int NA_ = Stager<BM, A_KMAJ, NT>::NV, NB_ = Stager<BN, B_KMAJ, NT>::NV;
+    if (PIPE) {
+        const int k1 = k_begin + (nk > 1 ? BK : 0);
+        sa.load(ra, k1, K);
+        sb.load(rb, k1, K);
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) {
+        if (!PIPE && more) {
             sa.load(ra, k_begin + (kt + 1) * BK, K);
             sb.load(rb, k_begin + (kt + 1) * BK, K);
         }
-        const unsigned char* ab = smem_raw + cur * BUF_BYTES + a_frag;
-        const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES + b_frag;
+        const int k2 = k_begin + (kt + 2 < nk ? kt + 2 : nk - 1) * BK;
+        unsigned char* nxt = smem_raw + (cur ^ 1) * BUF_BYTES;
+        const unsigned char* ab = smem_raw + cur * BUF_BYTES;
+        const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[NS][2], fb[NS][2];
@@ -156,13 +191,28 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    fa[s][m] = *reinterpret_cast<const bf16x8*>(ab + s * A_BYTES + m * 32 * ROW_B + ks * 32);
+                    fa[s][m] = *reinterpret_cast<const bf16x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    fb[s][n] = *reinterpret_cast<const bf16x8*>(bb + s * B_BYTES + n * 32 * ROW_B + ks * 32);
+                    fb[s][n] = *reinterpret_cast<const bf16x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
+                if (PIPE) {
+                    const int g = ks * 2 + m;
+#pragma unroll
+                    for (int i = 0; i < NA_; ++i)
+                        if (i * 4 / NA_ == g) {
+                            sa.template store_item<NS>(i, ra[i], nxt, A_BYTES);
+                            sa.load_item(i, ra[i], k2, K);
+                        }
+#pragma unroll
+                    for (int i = 0; i < NB_; ++i)
+                        if (i * 4 / NB_ == g) {
+                            sb.template store_item<NS>(i, rb[i], nxt + NS * A_BYTES, B_BYTES);
+                            sb.load_item(i, rb[i], k2, K);
+                        }
+                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     // smallest terms first
@@ -175,13 +225,10 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
                 }
-        }
-        if (NBUF == 2) {
-            if (more) {
-                unsigned char* nb = smem_raw + (cur ^ 1) * BUF_BYTES;
-                sa.template store<NS>(ra, nb, A_BYTES);
-                sb.template store<NS>(rb, nb + NS * A_BYTES, B_BYTES);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
             }
+        }
+        if (PIPE) {
             __syncthreads();
             cur ^= 1;
         } else {
@@ -221,7 +268,7 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(const float* __restrict
 // global->LDS bytes and 3/4 of the LDS fragment bytes per flop.  LDS rows are unpadded 64 bytes
 // (so that two buffers of 2 x 512 rows fit) with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3:
 // the 16 lanes of a ds_read_b128 group (4 row quads) then hit 16 distinct 4-bank slots.
-constexpr int BT = 256, ROW64 = 64;
+constexpr int BT = 256, ROW64 = ROW_B;
 
 #ifdef E3D_STAMPS   // lab builds only (tools/lab_gemm_stamps.py): in-kernel phase time stamps of one workgroup
 __device__ long long e3d_stamps[2][32][8];
@@ -237,8 +284,6 @@ __device__ long long e3d_stamps[2][32][8];
 #define STAMP(slot) do {} while (0)
 #define STAMP_K(i) do {} while (0)
 #endif
-
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 // WR x WC waves, each 128x64: <2,4> = 256x256 tile, 512 threads, two LDS buffers, one block per CU;
 // <2,2> = 256x128 tile, 256 threads, ONE LDS buffer (48 KB) so that two blocks share a CU.
@@ -624,6 +669,10 @@ int launch256(const float* A, int64_t lda, const float* W, const float* bias, fl
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
+                   int M, int N, int K, hipStream_t s);
+
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
            int M, int N, int K, hipStream_t s) {
@@ -642,19 +691,36 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
         (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
         return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1)>(A, lda, B, bias, out, ldc, M, N, K, s);
+    // a handful of 256-row tiles (single-pocket sampling): 128-row tiles
+    static int wm_pref = -1;   // E3D_GEMM_WM = 2 / 4 forces a form (experiments)
+    if (wm_pref < 0) {
+        const char* e = getenv("E3D_GEMM_WM");
+        wm_pref = e ? atoi(e) : 0;
+    }
+    const int tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
+    // (measured: a win only for very small grids -- single-pocket sampling; at M = 4096 the 256-row form is 25 % faster)
+    if (NS == 2 && (wm_pref == 2 || (wm_pref == 0 && tiles256 < 32 && !A_KMAJ && !B_KMAJ)))
+        return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+}
+
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
+                   int M, int N, int K, hipStream_t s) {
+    constexpr int BM = WM * 64;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count
     int splits = 1;
-    if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 128 && K >= 1024) {
-        splits = 256 / (tiles_m * tiles_n);
+    if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 32 * WM && K >= 1024) {
+        splits = 64 * WM / (tiles_m * tiles_n);
         splits = splits > 16 ? 16 : splits;
         while (splits > 1 && K / splits < 256) --splits;
     }
@@ -670,8 +736,8 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
             return (int)e;
         }
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ>), dim3(tiles_m * tiles_n, splits), dim3(512), lds, s,
-                       A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>), dim3(tiles_m * tiles_n, splits), dim3(WM * 128),
+                       lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
     return e3d_launch_status("e3d_gemm_f32_split");
 }
 

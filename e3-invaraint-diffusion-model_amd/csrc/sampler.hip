@@ -18,7 +18,16 @@ __device__ __forceinline__ float wrap_pi(float v) {
 
 __global__ __launch_bounds__(256) void ddpm_step_wrap_kernel(
     const float* __restrict__ x, const float* __restrict__ eps_hat, const float* __restrict__ noise,
-    float sra, float beta, float s1m, float sigma, int wrap, float* __restrict__ out, int64_t n4, int64_t n) {
+    float sra, float beta, float s1m, float sigma, const float* __restrict__ coef_table,
+    const int64_t* __restrict__ t_dev, int wrap, float* __restrict__ out, int64_t n4, int64_t n) {
+    if (coef_table) {   // graph-replayable form: the step index lives on the device, the coefficients in a [T,4] table
+        const int64_t t = t_dev[0];
+        sra = coef_table[4 * t];
+        beta = coef_table[4 * t + 1];
+        s1m = coef_table[4 * t + 2];
+        sigma = coef_table[4 * t + 3];
+        if (sigma == 0.f) noise = nullptr;   // t == 0: the mean, exactly as the scalar form
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
@@ -187,8 +196,23 @@ extern "C" int e3d_ddpm_step_wrap(const float* x, const float* eps_hat, const fl
     int64_t blocks = (n4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(ddpm_step_wrap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, eps_hat,
-                       sigma != 0.f ? noise : nullptr, sqrt_recip_alpha, beta, sqrt_one_minus_ab, sigma, wrap, out, n4, n);
+                       sigma != 0.f ? noise : nullptr, sqrt_recip_alpha, beta, sqrt_one_minus_ab, sigma, nullptr, nullptr, wrap,
+                       out, n4, n);
     return e3d_launch_status("e3d_ddpm_step_wrap");
+}
+
+extern "C" int e3d_ddpm_step_wrap_table(const float* x, const float* eps_hat, const float* noise,
+                                        const float* coef_table, const int64_t* t_dev, int wrap, float* out,
+                                        int64_t n, void* stream) {
+    E3D_REQUIRE(x && eps_hat && noise && coef_table && t_dev && out && n > 0, "ddpm_step_wrap_table: bad arguments");
+    E3D_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)eps_hat % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                    ((uintptr_t)noise % 16) == 0, "ddpm_step_wrap_table: pointers must be 16B aligned");
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(ddpm_step_wrap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, eps_hat, noise,
+                       0.f, 0.f, 1.f, 0.f, coef_table, t_dev, wrap, out, n4, n);
+    return e3d_launch_status("e3d_ddpm_step_wrap_table");
 }
 
 extern "C" int e3d_q_sample_wrap(const float* x0, const float* noise, const int64_t* t,

@@ -142,13 +142,16 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         args = (_p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0),
                 _p(v), Lk * v.stride(0), v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse),
                 B, nh, Lq, Lk)
-        if drop is not None and drop[0] > 0:
-            hip.check(hip.lib().e3d_relkey_attn_fwd_split_drop(*args, terms or 6, float(drop[0]), int(drop[1]), _stream()),
-                      "e3d_relkey_attn_fwd_split_drop")
-        elif terms == 0:
+        dropping = drop is not None and drop[0] > 0
+        if terms == 0 and not dropping:
             hip.check(hip.lib().e3d_relkey_attn_fwd(*args, _stream()), "e3d_relkey_attn_fwd")
         else:
-            hip.check(hip.lib().e3d_relkey_attn_fwd_split(*args, terms, _stream()), "e3d_relkey_attn_fwd_split")
+            # scratch for the bf16 planes of dist_emb (cooperative kernel): a torch allocation keeps the call
+            # free of stream-ordered hipMallocAsync, so the launch sequence can be captured into a HIP graph
+            scratch = torch.empty_like(dist_emb) if dist_emb is not None else None
+            p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)
+            hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), _stream()),
+                      "e3d_relkey_attn_fwd_split_ex")
     return (out, lse) if want_lse else out
 
 
@@ -215,6 +218,21 @@ def ddpm_step_wrap(x, eps_hat, noise, sqrt_recip_alpha, beta, sqrt_one_minus_ab,
     hip.check(hip.lib().e3d_ddpm_step_wrap(_p(x), _p(eps_hat), _p(noise), sqrt_recip_alpha, beta,
                                            sqrt_one_minus_ab, sigma, int(wrap), _p(out), x.numel(), _stream()),
               "e3d_ddpm_step_wrap")
+    return out
+
+
+def ddpm_step_wrap_table(x, eps_hat, noise, coef_table, t_dev, wrap=True, out=None):
+    """ddpm_step_wrap with the step index on the device (``t_dev`` int64, first element) and the four
+    coefficients in ``coef_table`` [T,4]: nothing host-side changes between steps (HIP-graph replay)."""
+    for n, t in (("x", x), ("eps_hat", eps_hat), ("noise", noise), ("coef_table", coef_table)):
+        _chk(t, "ddpm_step_wrap_table." + n)
+    _chk(t_dev, "ddpm_step_wrap_table.t_dev", torch.int64)
+    assert x.is_contiguous() and eps_hat.is_contiguous() and noise.is_contiguous() and coef_table.is_contiguous()
+    assert coef_table.dim() == 2 and coef_table.shape[1] == 4
+    if out is None:
+        out = torch.empty_like(x)
+    hip.check(hip.lib().e3d_ddpm_step_wrap_table(_p(x), _p(eps_hat), _p(noise), _p(coef_table), _p(t_dev), int(wrap),
+                                                 _p(out), x.numel(), _stream()), "e3d_ddpm_step_wrap_table")
     return out
 
 

@@ -16,6 +16,7 @@ if __package__ in (None, ""):  # executed as a script from inside this directory
     _g.load_package()
     __package__ = "e3diff_amd.structure_model"
 
+import os
 import pickle
 
 import torch
@@ -103,21 +104,93 @@ def _reverse_step(model, ligand_mask, x_t, receptor_seq, receptor_mask, receptor
     return ops.ddpm_step_wrap(x_c, eps_hat.contiguous(), noise, sra, beta, s1m, sigma, wrap=wrap, out=out)
 
 
+
+
+class GraphedReverseStep:
+    """One reverse step (decoder forward + DDPM update + wrap) captured once into a HIP graph and replayed
+    per step.  Everything that varies between steps lives on the device: the step index (``self.t``,
+    also the row of the [T,4] coefficient table read by ``e3d_ddpm_step_wrap_table``), the state
+    ``self.x`` and the noise draw.  Results are bit-identical to the eager path for the same noise.
+
+    Opt-in (``use_graph=True`` / E3D_SAMPLE_GRAPH=1): measured on MI355X at B=1, L=64 a replay takes
+    3.9 ms per step against 3.8 ms of eager launches -- the kernel trace shows the GPU 100 % busy with
+    back-to-back kernels (mean gap 0.1 us), i.e. single-pocket sampling is bound by the latency of its
+    ~190 dependent small kernels (a 6-workgroup GEMM takes ~40 us), not by host launch cost."""
+
+    def __init__(self, model, ligand_mask, cache, tab, x_like, wrap=True, draw=True):
+        """``draw``: the graph draws its own N(0,1) noise each replay; False: ``step`` takes the draw (parity tests)."""
+        dev = x_like.device
+        self.model, self.mask, self.cache, self.wrap = model, ligand_mask, cache, wrap
+        self.x = torch.empty_like(x_like)
+        self.out = torch.empty_like(x_like)
+        self.noise = torch.zeros_like(x_like)
+        self.t = torch.zeros((x_like.shape[0],), device=dev, dtype=torch.long)
+        self.coef = torch.stack([tab.sqrt_recip_alphas, tab.betas, tab.sqrt_one_minus_alphas_cumprod, tab.sigma],
+                                dim=1).float().contiguous().to(dev)
+        self.draw = draw
+        self.x.copy_(x_like)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):      # warm-up off the capture: first-launch attribute calls, allocator
+            for _ in range(2):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+
+    def _body(self):
+        eps_hat = self.model.decode(self.t, self.x, self.mask, self.cache)
+        if self.draw:
+            self.noise.normal_()
+        ops.ddpm_step_wrap_table(self.x, eps_hat.contiguous(), self.noise, self.coef, self.t, wrap=self.wrap, out=self.out)
+
+    def step(self, i, x, noise=None):
+        """x_t -> x_{t-1} for step index i; returns the graph's output buffer (overwritten by the next call)."""
+        if (noise is not None) == self.draw:
+            raise ValueError("this graph was captured %s injected noise" % ("without" if self.draw else "with"))
+        self.t.fill_(i)
+        if x is not self.x:
+            self.x.copy_(x)
+        if noise is not None:
+            self.noise.copy_(noise)
+        self.graph.replay()
+        return self.out
+
+
+def _use_graph(x):
+    return os.environ.get("E3D_SAMPLE_GRAPH") == "1"
+
+
 @torch.no_grad()
 def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_seq, receptor_mask,
                   receptor_angle, total_timesteps: int, betas, disable_pbar: bool = False,
-                  noises=None, return_device: bool = False, step: int = None) -> torch.Tensor:
+                  noises=None, return_device: bool = False, step: int = None, use_graph: bool = None) -> torch.Tensor:
     """Full reverse chain; returns [T/STEP, B, L, n_ft] (on the host like the reference,
-    sample.py:101-144, unless ``return_device``).  ``noises`` [T/STEP,B,L,n_ft] injects the draws."""
+    sample.py:101-144, unless ``return_device``).  ``noises`` [T/STEP,B,L,n_ft] injects the draws.
+    ``use_graph``: replay one captured HIP graph per step (opt-in, also E3D_SAMPLE_GRAPH=1 -- see
+    GraphedReverseStep for why it is not the default); falls back to eager launches if the capture fails."""
     step = STEP if step is None else step
     tab = _tables(betas)
     order = list(reversed(range(0, total_timesteps, step)))
     x = ligand_angle_noise.contiguous().float()
     cache = model.encode_receptor(receptor_seq, receptor_angle, receptor_mask)
     traj = torch.empty((len(order),) + tuple(x.shape), device=x.device, dtype=torch.float32)
+    graphed = None
+    if (_use_graph(x) if use_graph is None else use_graph) and len(order) > 4:
+        try:
+            graphed = GraphedReverseStep(model, ligand_mask.contiguous().float(), cache, tab, x, draw=noises is None)
+        except Exception as e:   # noqa: BLE001 -- any capture problem: eager launches are always correct
+            import warnings
+            warnings.warn(f"HIP-graph capture of the reverse step failed ({type(e).__name__}: {e}); using eager launches")
+            graphed = None
     for n, i in enumerate(order):
-        x = _reverse_step(model, ligand_mask, x, None, None, None, i, tab,
-                          None if noises is None else noises[n], cache, traj[n], wrap=True)
+        if graphed is not None:
+            x = graphed.step(i, graphed.out if n else x, None if noises is None else noises[n].contiguous())
+            traj[n].copy_(x)
+        else:
+            x = _reverse_step(model, ligand_mask, x, None, None, None, i, tab,
+                              None if noises is None else noises[n], cache, traj[n], wrap=True)
     return traj if return_device else traj.cpu()
 
 

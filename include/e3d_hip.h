@@ -122,6 +122,14 @@ int e3d_ddpm_step_wrap(const float* x, const float* eps_hat, const float* noise,
                        float sqrt_recip_alpha, float beta, float sqrt_one_minus_ab, float sigma,
                        int wrap, float* out, int64_t n, void* stream);
 
+/* e3d_ddpm_step_wrap with the step index on the device: coefficients are row t_dev[0] of
+ * coef_table [T,4] = (sqrt_recip_alpha, beta, sqrt_one_minus_alphas_cumprod, sigma); sigma == 0 (t == 0)
+ * skips the noise term exactly like the scalar form.  No host scalar changes from step to step, so a
+ * captured hipGraph of the whole reverse step can be replayed (structure_model/sample.py). */
+int e3d_ddpm_step_wrap_table(const float* x, const float* eps_hat, const float* noise,
+                             const float* coef_table, const int64_t* t_dev, int wrap, float* out,
+                             int64_t n, void* stream);
+
 /* Forward noising q(x_t | x_0) with wrap (structure_model/dataset.py:211-228):
  *   out[b] = wrap(sqrt_ab[t[b]] * x0[b] + sqrt_1mab[t[b]] * noise[b]),  per = elements per item. */
 int e3d_q_sample_wrap(const float* x0, const float* noise, const int64_t* t,
@@ -192,6 +200,15 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
                                    const float* dist_emb, int P, const float* key_mask, float* out,
                                    float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                    uint64_t drop_seed, void* stream);
+
+/* The full form of the two above: ``e_scratch`` (device, >= (2P-1)*64*4 bytes, or NULL) receives the bf16
+ * hi/lo planes of dist_emb that the cooperative kernel reads; with NULL the library takes a stream-ordered
+ * allocation (hipMallocAsync), which callers that capture the stream into a hipGraph should avoid. */
+int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                 int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                                 const float* dist_emb, int P, const float* key_mask, float* out,
+                                 float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
+                                 uint64_t drop_seed, void* e_scratch, void* stream);
 
 /* e3d_relkey_attn_bwd for a forward that used (drop_p, drop_seed). */
 int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""BASELINE config 4, one GPU's share: joint structure -> sequence sampling of 128 synthetic pockets
+(L = 128): stage 1 = structure p_sample_loop over T = 1000 steps, stage 2 = sequence denoise over 50 steps
+(DiscreteUniformTransition, diverse=True) on the generated last-step angles, handed over on the device.
+
+    python tools/bench_joint.py [--batch 128] [--seq-len 128] [--t-structure 1000] [--t-sequence 50]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__  # noqa: E402
+
+pkg = __graft_entry__.load_package()
+from helpers import synthetic_pockets  # noqa: E402
+from e3diff_amd.bert import BertConfig  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--t-structure", type=int, default=1000)
+    ap.add_argument("--t-sequence", type=int, default=50)
+    a = ap.parse_args()
+    B, L = a.batch, a.seq_len
+    from e3diff_amd.structure_model import sample as SS
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as SM
+    from e3diff_amd.structure_model.utils import CosineTables, modulo_with_wrapped_range
+    from e3diff_amd.sequence_model import sample as QS
+    from e3diff_amd.sequence_model import sample_by_generated_angles as QJ
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    from e3diff_amd.sequence_model.utils import DiscreteUniformTransition, PredefinedNoiseScheduleDiscrete
+
+    def cfgs(layers):
+        c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=layers,
+                 max_position_embeddings=L, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        return BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True)
+
+    torch.manual_seed(0)
+    smodel = SM(*cfgs(12), feature_names=list("abcdefgh"), loss_func=[SM.diheral_loss_func] * 8).eval().to(DEV)
+    qmodel = PeptideDiff(*cfgs(6), feature_names=list("ACDEFGHIKLMNPQRSTVWY"), loss_func=torch.nn.CrossEntropyLoss(),
+                         noise_schedule="cosine", timesteps=a.t_sequence).eval().to(DEV)
+    pk = synthetic_pockets(B, L, seed=0, with_ligand_seq=True)
+    dpk = {k: v.to(DEV) for k, v in pk.items() if torch.is_tensor(v)}
+    tab = CosineTables(a.t_structure)
+    x_T = modulo_with_wrapped_range(torch.randn(B, L, 8, device=DEV))
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    # warm-up (first launches, allocator)
+    SS.p_sample_loop(smodel, dpk["ligand_attn_mask"], x_T, dpk["receptor_seq"], dpk["receptor_attn_mask"],
+                     dpk["receptor_angles"], 4, CosineTables(4), disable_pbar=True, return_device=True, step=1)
+    t0 = sync()
+    traj = SS.p_sample_loop(smodel, dpk["ligand_attn_mask"], x_T, dpk["receptor_seq"], dpk["receptor_attn_mask"],
+                            dpk["receptor_angles"], a.t_structure, tab, disable_pbar=True, return_device=True, step=1)
+    t1 = sync()
+    angles = QJ.angles_from_trajectory(traj, dpk["ligand_attn_mask"])
+    schedule = PredefinedNoiseScheduleDiscrete("cosine", a.t_sequence).to(DEV)
+    ids, true_s, pred_s, rec = QJ.denoise(pk, angles, qmodel, schedule, DiscreteUniformTransition(20), True,
+                                          timesteps=a.t_sequence)
+    t2 = sync()
+    n1, n2 = a.t_structure, a.t_sequence
+    print(f"joint sampling, {B} pockets x L={L} on one GPU: structure {n1} steps {t1 - t0:.2f} s "
+          f"({B * n1 / (t1 - t0):.0f} pocket-steps/s, {1e3 * (t1 - t0) / n1:.2f} ms/step, encoder cached), "
+          f"sequence {n2} steps {t2 - t1:.2f} s ({B * n2 / (t2 - t1):.0f} pocket-steps/s, {1e3 * (t2 - t1) / n2:.2f} ms/step); "
+          f"total {t2 - t0:.2f} s = {B / (t2 - t0):.1f} pockets/s; trajectory kept on device "
+          f"({traj.numel() * 4 / 2**20:.0f} MiB)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
