@@ -15,6 +15,8 @@
 //     rows.
 // In-kernel stamps of the per-wave kernel showed each wave spending ~12k cycles per key tile for
 // ~1.2k cycles of MFMA work, the rest being its private load -> split -> LDS -> fragment chain.
+#include <type_traits>
+
 #include "e3d_common.h"
 
 namespace {
@@ -195,10 +197,23 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    int rot = 0, cur = 0;
+    // Ring addressing without per-tile integer math.  Tiles alternate PAR = 0 / 1 (ring rotation 0 / 32 rows, LDS
+    // buffer 0 / 1).  With rho = mfma32_row(r, half) = rp(r) + 4 half, rp(r) = (r & 3) + 8 (r >> 2) <= 27:
+    //   T^T row rho is written to ring row rho + rot:      ring_w[(rot + rp) * RING_LD]           (immediates)
+    //   score row rho reads window row x = qi - rho + 31 (0..62) at ring row x ^ rot:
+    //       rot = 0:  ring_e[(27 - rp) * RING_LD]                                                 (immediates)
+    //       rot = 32: ring[rd_odd[r]]                                           (16 precomputed lane offsets)
+    float* const ring_w = ring + 4 * half * RING_LD + qi;
+    const float* const ring_e = ring + (qi + 31 - 4 * half - 27) * RING_LD + qi;
+    int rd_odd[16];
+    if (RELKEY) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rd_odd[r] = (((qi - mfma32_row(r, half) + 31) ^ 32) * RING_LD + qi);
+    }
 
-    for (int kt = 0; kt < k_tiles; ++kt) {
-        const unsigned char* buf = smem_raw + cur * KV_BUF_B;
+    auto tile = [&](auto par_tag, int kt) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const unsigned char* buf = smem_raw + PAR * KV_BUF_B;
         const bool more = kt + 1 < k_tiles;
         if (more) stage_load((kt + 1) * 32);
 
@@ -217,17 +232,14 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             const f32x16 t = dot_q(ef);
             if (more) e_load(q0 - (kt + 1) * 32 - 31 + P - 1);   // next tile's block, in flight under the softmax
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ring[((mfma32_row(r, half) + rot) & 63) * RING_LD + qi] = t[r];
+            for (int r = 0; r < 16; ++r) ring_w[(32 * PAR + (r & 3) + 8 * (r >> 2)) * RING_LD] = t[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int x = qi - mfma32_row(r, half) + 31;
-                s[r] += ring[((x + rot) & 63) * RING_LD + qi];
-            }
+            for (int r = 0; r < 16; ++r)
+                s[r] += PAR ? ring[rd_odd[r]] : ring_e[(27 - ((r & 3) + 8 * (r >> 2))) * RING_LD];
             __builtin_amdgcn_wave_barrier();
-            rot ^= 32;
         }
 
         const float* kbias = reinterpret_cast<const float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B);
@@ -273,9 +285,12 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             o1 = mfma3(a1, pb, o1);
         }
 
-        if (more) stage_store(smem_raw + (cur ^ 1) * KV_BUF_B);
+        if (more) stage_store(smem_raw + (PAR ^ 1) * KV_BUF_B);
         __syncthreads();
-        cur ^= 1;
+    };
+    for (int kt = 0; kt < k_tiles; kt += 2) {
+        tile(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < k_tiles) tile(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

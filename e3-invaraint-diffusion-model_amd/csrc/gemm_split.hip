@@ -494,6 +494,14 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 // latency (~11k cycles per tile in the stamps) and the workgroup relaunch are paid once per CU.
 // Staging addresses are a wave-uniform tile base (SGPRs) plus a per-item 32-bit offset that is the
 // same for every tile.
+// -DE3D_NT_STORES (lab): streaming (non-temporal) output stores.  +2-3.5 % per launch in isolation, nothing inside
+// the model step (the consumer kernel then finds less of the output in the memory-side cache), so not the default.
+#ifdef E3D_NT_STORES
+#define E3D_STORE_OUT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define E3D_STORE_OUT(ptr, val) (*(ptr) = (val))
+#endif
+
 template <int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ W,
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                     float v = acc[m][n][r] + bv;
                     if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                     if (ACT == E3D_ACT_SILU) v = silu(v);
-                    o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+                    E3D_STORE_OUT(&o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc], v);
                 }
             }
         }
