@@ -67,23 +67,44 @@ __device__ __forceinline__ int v_pos(int kappa) {
     return (kappa & 0x13) | ((kappa & 4) << 1) | ((kappa & 8) >> 1);
 }
 
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, __bf16* __restrict__ hi,
-                                                           __bf16* __restrict__ lo, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const float v = x[i];
-        const __bf16 p = (__bf16)v;
-        hi[i] = p;
-        lo[i] = (__bf16)(v - (float)p);
+// Distance table -> bf16 hi/lo planes in MFMA-FRAGMENT order.  Every 32-row block of E the kernel touches starts
+// at a row e0 = P + 32 m (q0 and r0 are multiples of 32), m = -J0 .. J0 - 1 with J0 = ceil(L / 32), so the
+// fragments of block j = m + J0 are laid out as [j][plane][kb][lane] x 16 bytes: a wave's E load is then 8
+// fully coalesced 1-KB reads instead of 8 reads of 64 scattered 16-byte pieces (measured: 17 % of the kernel).
+// Rows outside [0, 2P-2] (never paired with a valid (query, key)) are clamped.
+__global__ __launch_bounds__(256) void e_fragments_kernel(const float* __restrict__ e, bf16x8* __restrict__ frag, int P,
+                                                          int J0, int n_items) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // item = ((j * 2 + plane) * 4 + kb) * 64 + lane
+    if (i >= n_items) return;
+    const int lane = i & 63, kb = (i >> 6) & 3, plane = (i >> 8) & 1, j = i >> 9;
+    const int row = min(max(P + 32 * (j - J0) + (lane & 31), 0), 2 * P - 2);
+    const float* src = e + row * D + 16 * kb + 8 * (lane >> 5);
+    bf16x8 out;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float v = src[t];
+        const __bf16 hi = (__bf16)v;
+        out[t] = plane ? (__bf16)(v - (float)hi) : hi;
     }
+    frag[i] = out;
 }
+
+#ifdef E3D_ATTN_STAMPS   // lab builds only (tools/lab_attn_stamps.py): phase time stamps of one wave
+__device__ long long e3d_attn_stamps[16][8];
+#define ASTAMP(slot)                                                                                     \
+    do {                                                                                                 \
+        if (blockIdx.x == 1000 && wid == 1 && lane == 0 && kt < 16) e3d_attn_stamps[kt][slot] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define ASTAMP(slot) do {} while (0)
+#endif
 
 template <int W, bool RELKEY>
 __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
-    int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const __bf16* __restrict__ e_hi,
-    const __bf16* __restrict__ e_lo, int P, const float* __restrict__ key_mask, float* __restrict__ out,
-    float* __restrict__ lse, int nh, int Lq, int Lk, int groups_per_bh, int skip_padded_tiles) {
+    int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const bf16x8* __restrict__ e_frag,
+    int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq, int Lk,
+    int groups_per_bh, int skip_padded_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = W * 64, NI = 512 / NT;   // float4 staging items per thread, for K and for V
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -126,31 +147,36 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     }
 
     // cooperative staging: item i of this thread = row (f >> 4), head dims 4 (f & 15) .. +3, f = tid + NT i
-    f32x4 sk[NI], sv[NI];
-    float sbias = 0.f;
-    auto stage_load = [&](int r0) {
+    // Two register sets when they are small (W >= 4: one or two float4 per operand): tile t+2 is loaded while
+    // tile t is computed and tile t+1 (loaded a tile earlier) is split and stored -- the global latency
+    // (stamps: 2-3k cycles under load) then never shows.  Narrow workgroups keep one set (distance 1).
+    constexpr bool DEEP = NI <= 2;
+    constexpr int NSET = DEEP ? 2 : 1;
+    f32x4 sk[NSET][NI], sv[NSET][NI];
+    float smask[NSET];
+    auto stage_load = [&](auto set_tag, int r0) {
+        constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int f = tid + NT * i;
             const int key = min(r0 + (f >> 4), Lk - 1);
-            sk[i] = *reinterpret_cast<const f32x4*>(kb_ + (unsigned)(key * (int)k_rs + 4 * (f & 15)));
-            sv[i] = *reinterpret_cast<const f32x4*>(vb_ + (unsigned)(key * (int)v_rs + 4 * (f & 15)));
+            sk[SET][i] = *reinterpret_cast<const f32x4*>(kb_ + (unsigned)(key * (int)k_rs + 4 * (f & 15)));
+            sv[SET][i] = *reinterpret_cast<const f32x4*>(vb_ + (unsigned)(key * (int)v_rs + 4 * (f & 15)));
         }
-        if (tid < 32) {
-            const int key = r0 + tid;
-            sbias = -INFINITY;
-            if (key < Lk) sbias = mb ? (1.0f - mb[key]) * -10000.0f : 0.f;
-        }
+        // key-mask value of key r0 + (tid & 31): loaded by every thread (no branch around a load: hipcc then
+        // counts vmcnt exactly), used by the first 32
+        smask[SET] = mb ? mb[min(r0 + (tid & 31), Lk - 1)] : 1.0f;
     };
-    auto stage_store = [&](unsigned char* buf) {
+    auto stage_store = [&](auto set_tag, int r0, unsigned char* buf) {
+        constexpr int SET = decltype(set_tag)::value;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int f = tid + NT * i, row = f >> 4, c4 = f & 15;
             bf16x4 hi, lo;
-            split4x2(sk[i], hi, lo);
+            split4x2(sk[SET][i], hi, lo);
             *reinterpret_cast<bf16x4*>(buf + row * K_ROW_B + 8 * c4) = hi;
             *reinterpret_cast<bf16x4*>(buf + K_PLANE_B + row * K_ROW_B + 8 * c4) = lo;
-            split4x2(sv[i], hi, lo);
+            split4x2(sv[SET][i], hi, lo);
             unsigned char* vt = buf + 2 * K_PLANE_B + (4 * c4) * V_ROW_B + 2 * v_pos(row);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -158,19 +184,22 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
                 *reinterpret_cast<__bf16*>(vt + V_PLANE_B + e * V_ROW_B) = lo[e];
             }
         }
-        if (tid < 32) reinterpret_cast<float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B)[tid] = sbias;
+        if (tid < 32)
+            reinterpret_cast<float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B)[tid] =
+                r0 + tid < Lk ? (1.0f - smask[SET]) * -10000.0f : -INFINITY;
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
 
-    // rel-key: E fragments of the 32-row block starting at distance-table row e0 (rows clamped)
+    // rel-key: E fragments of block j (distance-table rows P + 32 (j - J0) .. + 31) from the fragment-order planes
     bf16x8 ef[4][2];
-    auto e_load = [&](int e0) {
-        const int row = min(max(e0 + qi, 0), 2 * P - 2);
-        const __bf16* ph = e_hi + row * D + 8 * half;
-        const __bf16* pl = e_lo + row * D + 8 * half;
+    const int J0 = (Lk + 31) >> 5, qt = q0 >> 5;
+    auto e_load = [&](int j) {
+        const bf16x8* pj = e_frag + (size_t)j * 512 + lane;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            ef[kb][0] = *reinterpret_cast<const bf16x8*>(ph + 16 * kb);
-            ef[kb][1] = *reinterpret_cast<const bf16x8*>(pl + 16 * kb);
+            ef[kb][0] = pj[kb * 64];
+            ef[kb][1] = pj[256 + kb * 64];
         }
     };
     auto dot_q = [&](const bf16x8 (&x)[4][2]) {
@@ -182,15 +211,16 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         return acc;
     };
 
-    stage_load(0);
+    stage_load(Set0{}, 0);
     if (RELKEY) {
-        e_load(q0 + 1 + P - 1);   // the block "before" key tile 0 fills the upper half of the ring
+        e_load(qt + J0);          // rows q0 + P ..: the block "before" key tile 0 fills the upper half of the ring
         const f32x16 t = dot_q(ef);
 #pragma unroll
         for (int r = 0; r < 16; ++r) ring[(32 + mfma32_row(r, half)) * RING_LD + qi] = t[r];
-        e_load(q0 - 31 + P - 1);
+        e_load(qt - 1 + J0);      // key tile 0: rows q0 - 32 + P ..
     }
-    stage_store(smem_raw);
+    stage_store(Set0{}, 0, smem_raw);
+    if (DEEP) stage_load(Set1{}, (k_tiles > 1 ? 1 : 0) * 32);
     __syncthreads();
 
     f32x16 o0, o1;
@@ -215,7 +245,9 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         constexpr int PAR = decltype(par_tag)::value;
         const unsigned char* buf = smem_raw + PAR * KV_BUF_B;
         const bool more = kt + 1 < k_tiles;
-        if (more) stage_load((kt + 1) * 32);
+        const int kt_next = more ? kt + 1 : kt;   // last tile: harmless re-load (no branch around the loads:
+        ASTAMP(0);                                //  hipcc then counts vmcnt exactly instead of draining to 0)
+        ASTAMP(1);
 
         f32x16 s;
         {   // S^T = K Q^T
@@ -228,9 +260,12 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             }
             s = dot_q(kf);
         }
+        ASTAMP(2);
         if (RELKEY) {
             const f32x16 t = dot_q(ef);
-            if (more) e_load(q0 - (kt + 1) * 32 - 31 + P - 1);   // next tile's block, in flight under the softmax
+#ifndef E3D_ABL_ELOAD   // lab ablation: wrong results, timing only
+            e_load(qt - kt_next - 1 + J0);   // next tile's block, in flight under the softmax
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) ring_w[(32 * PAR + (r & 3) + 8 * (r >> 2)) * RING_LD] = t[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -241,6 +276,13 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
                 s[r] += PAR ? ring[rd_odd[r]] : ring_e[(27 - ((r & 3) + 8 * (r >> 2))) * RING_LD];
             __builtin_amdgcn_wave_barrier();
         }
+        // K/V of the next tile: issued only now -- the T MFMAs above wait for the E fragments with an in-order
+        // vmcnt, so any younger load in flight at that point would be waited for as well (stamps: ~1500 cycles)
+        // (two sets: tile t+2 into the set whose tile-t data was stored a tile ago; clamped re-loads at the end)
+        const int kt_ld = DEEP ? (kt + 2 < k_tiles ? kt + 2 : k_tiles - 1) : kt_next;
+        if (PAR == 0) stage_load(Set0{}, kt_ld * 32);
+        else stage_load(Set1{}, kt_ld * 32);
+        ASTAMP(3);
 
         const float* kbias = reinterpret_cast<const float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B);
         float tmax = -INFINITY;
@@ -266,6 +308,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        ASTAMP(4);
 
         // O^T += V^T P^T: two 16-key steps; P^T registers 8 st .. 8 st + 7 are the B operand, the A
         // operand rows are head dims qi (o0) and 32 + qi (o1) of the transposed V image
@@ -285,8 +328,14 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             o1 = mfma3(a1, pb, o1);
         }
 
-        if (more) stage_store(smem_raw + (PAR ^ 1) * KV_BUF_B);
+        ASTAMP(5);
+        if (more) {   // tile t+1: from the other set when there are two, from the one just loaded otherwise
+            if (DEEP == (PAR == 0)) stage_store(Set1{}, kt_next * 32, smem_raw + (PAR ^ 1) * KV_BUF_B);
+            else stage_store(Set0{}, kt_next * 32, smem_raw + (PAR ^ 1) * KV_BUF_B);
+        }
+        ASTAMP(6);
         __syncthreads();
+        ASTAMP(7);
     };
     for (int kt = 0; kt < k_tiles; kt += 2) {
         tile(std::integral_constant<int, 0>{}, kt);
@@ -321,7 +370,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
 
 template <int W, bool RELKEY>
 int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
-             int64_t v_bs, int64_t v_rs, const __bf16* e_hi, const __bf16* e_lo, int P, const float* key_mask,
+             int64_t v_bs, int64_t v_rs, const bf16x8* e_frag, int P, const float* key_mask,
              float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip, hipStream_t s) {
     const size_t lds = 2 * KV_BUF_B + (size_t)W * RING_F * sizeof(float);
     static bool attr_set = false;
@@ -332,19 +381,19 @@ int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t
     }
     const int groups = q_tiles / W;
     hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
-                       k_rs, v, v_bs, v_rs, e_hi, e_lo, P, key_mask, out, lse, nh, Lq, Lk, groups, skip);
+                       k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, nh, Lq, Lk, groups, skip);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (cooperative)");
 }
 
 template <bool RELKEY>
 int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
-               const float* v, int64_t v_bs, int64_t v_rs, const __bf16* e_hi, const __bf16* e_lo, int P,
+               const float* v, int64_t v_bs, int64_t v_rs, const bf16x8* e_frag, int P,
                const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip,
                hipStream_t s) {
 #define E3D_COOP_CASE(w)                                                                                          \
     case w:                                                                                                       \
-        return launch_w<w, RELKEY>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_hi, e_lo, P, key_mask, out, lse, B, \
-                                   nh, Lq, Lk, q_tiles, skip, s)
+        return launch_w<w, RELKEY>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, B, nh, \
+                                   Lq, Lk, q_tiles, skip, s)
     switch (W) {
         E3D_COOP_CASE(8);
         E3D_COOP_CASE(4);
@@ -364,24 +413,38 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
                          void* e_scratch, hipStream_t s) {
     const int q_tiles = (Lq + 31) / 32;
-    const int W = q_tiles % 8 == 0 ? 8 : (q_tiles % 4 == 0 ? 4 : (q_tiles % 2 == 0 ? 2 : 1));
+    static int w_max = 0;   // E3D_ATTN_W caps the waves per workgroup (experiments)
+    if (!w_max) {
+        const char* e = getenv("E3D_ATTN_W");
+        w_max = e ? atoi(e) : 8;
+    }
+    int W = q_tiles % 8 == 0 ? 8 : (q_tiles % 4 == 0 ? 4 : (q_tiles % 2 == 0 ? 2 : 1));
+    while (W > w_max && W > 1) W >>= 1;
     if (!dist_emb)
-        return launch_any<false>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, nullptr, P, key_mask, out, lse,
-                                 B, nh, Lq, Lk, q_tiles, skip, s);
-    // distance table -> bf16 hi/lo planes (stream-ordered scratch: (2P-1) x 64 x 2 planes)
-    // -- into the caller's scratch (same byte size as dist_emb) or, without one, a stream-ordered allocation
-    const int n = (2 * P - 1) * D;
-    __bf16* planes = reinterpret_cast<__bf16*>(e_scratch);
+        return launch_any<false>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh, Lq,
+                                 Lk, q_tiles, skip, s);
+    // distance table -> fragment-order bf16 planes, into the caller's scratch (e3d_attn_scratch_bytes) or, without
+    // one, a stream-ordered allocation
+    const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
+    bf16x8* planes = reinterpret_cast<bf16x8*>(e_scratch);
     if (!planes) {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)2 * n * sizeof(__bf16), s);
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)n_items * sizeof(bf16x8), s);
         if (e != hipSuccess) {
             e3d_set_error("attn_coop: hipMallocAsync of the distance-table planes failed: %s", hipGetErrorString(e));
             return (int)e;
         }
     }
-    hipLaunchKernelGGL(split_planes_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dist_emb, planes, planes + n, n);
-    const int rc = launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, planes + n, P, key_mask, out,
-                                    lse, B, nh, Lq, Lk, q_tiles, skip, s);
+    hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
+    const int rc = launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh,
+                                    Lq, Lk, q_tiles, skip, s);
     if (!e_scratch) (void)hipFreeAsync(planes, s);
     return rc;
 }
+
+#ifdef E3D_ATTN_STAMPS
+extern "C" int e3d_debug_read_attn_stamps(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(e3d_attn_stamps), sizeof(long long) * 16 * 8);
+}
+#endif
+
+extern "C" int64_t e3d_attn_scratch_bytes(int Lk) { return (int64_t)2 * ((Lk + 31) / 32) * 512 * 16; }

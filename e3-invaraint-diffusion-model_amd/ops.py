@@ -148,7 +148,9 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         else:
             # scratch for the bf16 planes of dist_emb (cooperative kernel): a torch allocation keeps the call
             # free of stream-ordered hipMallocAsync, so the launch sequence can be captured into a HIP graph
-            scratch = torch.empty_like(dist_emb) if dist_emb is not None else None
+            scratch = None
+            if dist_emb is not None:
+                scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
             p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)
             hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), _stream()),
                       "e3d_relkey_attn_fwd_split_ex")

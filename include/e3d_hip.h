@@ -201,9 +201,11 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
                                    float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                    uint64_t drop_seed, void* stream);
 
-/* The full form of the two above: ``e_scratch`` (device, >= (2P-1)*64*4 bytes, or NULL) receives the bf16
- * hi/lo planes of dist_emb that the cooperative kernel reads; with NULL the library takes a stream-ordered
- * allocation (hipMallocAsync), which callers that capture the stream into a hipGraph should avoid. */
+/* The full form of the two above: ``e_scratch`` (device, >= e3d_attn_scratch_bytes(Lk) bytes, 16-byte
+ * aligned, or NULL) receives the fragment-order bf16 hi/lo planes of dist_emb that the cooperative kernel
+ * reads; with NULL the library takes a stream-ordered allocation (hipMallocAsync), which callers that
+ * capture the stream into a hipGraph should avoid. */
+int64_t e3d_attn_scratch_bytes(int Lk);
 int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                  int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                  const float* dist_emb, int P, const float* key_mask, float* out,
