@@ -263,9 +263,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         ASTAMP(2);
         if (RELKEY) {
             const f32x16 t = dot_q(ef);
-#ifndef E3D_ABL_ELOAD   // lab ablation: wrong results, timing only
             e_load(qt - kt_next - 1 + J0);   // next tile's block, in flight under the softmax
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) ring_w[(32 * PAR + (r & 3) + 8 * (r >> 2)) * RING_LD] = t[r];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

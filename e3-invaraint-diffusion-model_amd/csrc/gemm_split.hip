@@ -285,8 +285,8 @@ __device__ long long e3d_stamps[2][32][8];
 #define STAMP_K(i) do {} while (0)
 #endif
 
-// WR x WC waves, each 128x64: <2,4> = 256x256 tile, 512 threads, two LDS buffers, one block per CU;
-// <2,2> = 256x128 tile, 256 threads, ONE LDS buffer (48 KB) so that two blocks share a CU.
+// WR x WC waves, each 128x64: <2,4> = 256x256 tile, 512 threads, two LDS buffers, one workgroup per CU.
+// (<2,2> = 256x128 with one buffer and two workgroups per CU was measured 10 % slower and is not dispatched.)
 //
 // PIPE (two buffers): the staging of tile t+1 is spread over the 8 MFMA groups of iteration t instead
 // of being one phase at its end.  In-kernel time stamps showed the classic loop as a serial sum --
@@ -305,12 +305,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
                                                                         int tiles_n) {
     static_assert(!PIPE || NBUF == 2, "PIPE needs two LDS buffers");
     STAMP_K(0);   // kernel entry
-#ifdef E3D_STAGGER   // lab: phase-shift the CUs of an XCD so that their output bursts do not coincide
-    if (PIPE && blockIdx.x < 256) {
-        const int g = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < g; ++i) __builtin_amdgcn_s_sleep(E3D_STAGGER);
-    }
-#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = WR * WC * 64, TM = WR * 128, TN = WC * 64;
     constexpr int A_BYTES = TM * ROW64, B_BYTES = TN * ROW64;   // one operand, one part
@@ -657,8 +651,8 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
     return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
 }
 
-int g_tile_pref = -1;  // E3D_GEMM_TILE (experiments): 0 = 256x128 (8 waves of 64x64), 1 = 256x256 classic loop,
-                       // 2 = 256x128 two blocks per CU, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
+int g_tile_pref = -1;  // E3D_GEMM_TILE (A/B runs): 0 = 256x128 (8 waves of 64x64) for every shape, 1 = 256x256 classic
+                       // loop, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
 
 template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE = false>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
@@ -688,8 +682,6 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         const char* e = getenv("E3D_GEMM_TILE");
         g_tile_pref = e ? atoi(e) : 4;
     }
-    if (!A_KMAJ && !B_KMAJ && ldb == K && g_tile_pref == 2 && N % 128 == 0 && NS == 2)
-        return launch256<NS, ACT, 2, 2, 1>(A, lda, B, bias, out, ldc, M, N, K, s);
     if (!A_KMAJ && !B_KMAJ && N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && NS == 2 && K >= 2 * BK &&
         lda < (1 << 22) && (int64_t)(M / BT) * (N / BT) >= 256)
         return launch256p<ACT>(A, lda, B, bias, out, ldc, M, N, K, s);

@@ -35,6 +35,29 @@ def test_gemm_bias_act(pkg, hip, M, N, K, act, mode, tol):
     assert rel_err(got, ref) < tol
 
 
+@pytest.mark.parametrize("M,N,K,act", [(16384, 1024, 768, 1),     # >= 256 tiles of 256x256, M % 256 == 0: persistent kernel
+                                       (32768, 768, 1024, 0),     # 3 tiles per CU walk, K = 1024
+                                       (16400, 1024, 768, 2),     # ragged M: interleaved-staging kernel with row clamps
+                                       (16384, 1024, 32, 0)])     # a single k-tile: the stream wraps every tile
+def test_gemm_large_m_kernels(pkg, hip, M, N, K, act):
+    """The large-M forward kernels (256x256 tiles; bench.py shapes are of this kind) against fp64, with a
+    strided activation view (lda > K) as the packed QKV / KV consumers pass."""
+    wide = torch.randn(M, K + 64, generator=g(M))
+    a = wide[:, 32:32 + K]
+    w = torch.randn(N, K, generator=g(K)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(7))
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = {0: lambda x: x, 1: F.gelu, 2: F.silu}[act](ref).float()
+    a_dev = wide.to(DEV)[:, 32:32 + K]
+    for mode, tol in (("bf16x3", 3e-5), ("bf16x6", 5e-6)):
+        got = pkg.ops.gemm(a_dev, w.to(DEV), b.to(DEV), act, mode=mode)
+        assert rel_err(got, ref) < tol, mode
+        # every row and column block is right, not only the global max-norm
+        blk = (got.cpu() - ref).abs().view(-1, 16, N).amax(1).amax(1) if M % 16 == 0 else None
+        if blk is not None:
+            assert blk.max() < 3 * tol * ref.abs().max(), mode
+
+
 def test_gemm_split_handles_wide_dynamic_range(pkg, hip):
     """Split terms must reconstruct operands spanning many binades (outliers next to tiny values)."""
     a = torch.randn(300, 256, generator=g(1)) * torch.logspace(-6, 4, 256)[None, :]

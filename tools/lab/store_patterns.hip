@@ -10,6 +10,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int PAT>
 __global__ __launch_bounds__(512) void k(float* out, int ldc, int tiles_n) {
+    extern __shared__ float lds_pad[];   // dynamic LDS only to pin the occupancy (128 KB: one workgroup per CU, as the GEMM)
+    if (threadIdx.x == 9999) lds_pad[0] = 1.f;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wr = wid >> 2, wc = wid & 3;
     float* base = out + (size_t)(tm * 256 + wr * 128) * ldc + tn * 256 + wc * 64;
@@ -33,20 +35,27 @@ __global__ __launch_bounds__(512) void k(float* out, int ldc, int tiles_n) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int M = 65536, N = 768;
     float* out;
     hipMalloc(&out, (size_t)M * N * 4);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
+    const int lds = argc > 1 ? atoi(argv[1]) : 0;
+    if (lds) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    printf("dynamic LDS per workgroup: %d bytes\n", lds);
     for (int pat = 0; pat < 3; ++pat) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(a);
             for (int it = 0; it < 10; ++it) {
-                if (pat == 0) hipLaunchKernelGGL(k<0>, dim3(256 * 3), dim3(512), 0, 0, out, N, 3);
-                if (pat == 1) hipLaunchKernelGGL(k<1>, dim3(256 * 3), dim3(512), 0, 0, out, N, 3);
-                if (pat == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 3), dim3(512), 0, 0, out, N, 3);
+                if (pat == 0) hipLaunchKernelGGL(k<0>, dim3(256 * 3), dim3(512), lds, 0, out, N, 3);
+                if (pat == 1) hipLaunchKernelGGL(k<1>, dim3(256 * 3), dim3(512), lds, 0, out, N, 3);
+                if (pat == 2) hipLaunchKernelGGL(k<2>, dim3(256 * 3), dim3(512), lds, 0, out, N, 3);
             }
             hipEventRecord(b);
             hipEventSynchronize(b);
