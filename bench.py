@@ -226,6 +226,25 @@ def main():
             timed(cached_step, 1)
             elapsed_cached = timed(cached_step, args.steps)
 
+        # ... and with the frame trimmed to the longest ligand / pocket of the batch (p_sample_loop(trim_padding=True):
+        # valid positions unchanged, the decoder runs on 32 of the 256 ligand rows for BioLiP-shaped batches)
+        elapsed_trimmed = float("nan")
+        if not args.headline_only:
+            Ll, Lr = S.trimmed_length(pk["ligand_attn_mask"]), S.trimmed_length(pk["receptor_attn_mask"])
+            cache_t = model.encode_receptor(pk["receptor_seq"][:, :Lr].contiguous(), pk["receptor_angles"][:, :Lr].contiguous(),
+                                            pk["receptor_attn_mask"][:, :Lr].contiguous())
+            mask_t = pk["ligand_attn_mask"][:, :Ll].contiguous()
+            xa, xb = x[:, :Ll].contiguous(), torch.empty_like(x[:, :Ll].contiguous())
+            for k_steps in (1, args.steps):
+                barrier()
+                t0 = time.perf_counter()
+                for j in range(k_steps):
+                    y = S._reverse_step(model, mask_t, xa, None, None, None, 999 - j, tab, None, cache_t, xb, True)
+                    xa, xb = y, xa
+                barrier()
+                elapsed_trimmed = time.perf_counter() - t0
+            del cache_t
+
         # per-launch durations of the named kernels (HIP events on the launch stream), one dense step
         lib.e3d_attn_skip_padded_tiles(0)
         pkg.ops.TRACE = []
@@ -237,10 +256,10 @@ def main():
 
     modes = sorted(by_mode)
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip] + [by_mode[m] for m in modes],
+        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed] + [by_mode[m] for m in modes],
                          device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_cached, elapsed_skip, *rest = t.tolist()
+        elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed, *rest = t.tolist()
         by_mode = dict(zip(modes, rest))
 
     def avg_ms(name):
@@ -290,10 +309,13 @@ def main():
             "model_tflops": structure_flops_per_pocket(L) * B * world * args.steps / elapsed / 1e12,
             "value_encoder_cached": None if args.headline_only else B * world * args.steps / elapsed_cached,
             "value_padding_skip": None if args.headline_only else B * world / elapsed_skip,
+            "value_trimmed": None if args.headline_only else B * world * args.steps / elapsed_trimmed,
             "value_notes": "value = dense attention sweep over all padded keys + encoder recomputed every step "
                            "(every flop the reference does); value_padding_skip = product default (key sweep stops "
                            "after the last valid key, bit-identical results); value_encoder_cached = the sampler's "
-                           "real loop (pocket encoder + cross K/V once per batch), with the padding skip",
+                           "real loop (pocket encoder + cross K/V once per batch), with the padding skip; value_trimmed = the same loop "
+                           "on the frame trimmed to the batch's longest ligand / pocket (p_sample_loop(trim_padding=True), what "
+                           "structure_model/sample.py's sample() runs: valid positions unchanged)",
             # the binding roofline of the rel-key attention kernel: whichever of MFMA time (algorithmic flops /
             # peak) and HBM time (algorithmic bytes / 8 TB/s) is larger; frac = that time / measured time
             "roofline_attention": (lambda t_mfma, t_hbm: {

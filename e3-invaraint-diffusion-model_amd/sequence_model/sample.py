@@ -124,7 +124,7 @@ def sample_p_zs_given_zt_discrete(t, s, noised_data, pred_noise, noise_schedule,
 
 @torch.no_grad()
 def denoise(batch, model: PeptideDiff, noise_schedule, transition, diverse, x_T=None, us=None,
-            generated_angles=None, timesteps=None):
+            generated_angles=None, timesteps=None, trim_padding=False):
     """Full reverse chain over CONFIG["timesteps"] steps + recovery metrics (reference
     sample.py:181-229).  ``x_T`` / ``us`` inject the initial one-hot noise and the per-step
     uniforms (parity tests); ``generated_angles`` replaces the dataset's ligand angles
@@ -139,6 +139,17 @@ def denoise(batch, model: PeptideDiff, noise_schedule, transition, diverse, x_T=
     receptor_seq = batch["receptor_seq"].to(dev)
     receptor_angles = batch["receptor_angles"].to(dev)
     receptor_mask = batch["receptor_attn_mask"].to(dev)
+    if trim_padding:
+        # as structure_model/sample.py::p_sample_loop(trim_padding=True): padding cannot influence valid positions,
+        # and only valid positions are read below, so the chain runs on the frame of the longest ligand / pocket
+        from ..structure_model.sample import trimmed_length
+        Ll, Lr = trimmed_length(ligand_mask), trimmed_length(receptor_mask)
+        x, ligand_seq, ligand_mask = x[:, :Ll].contiguous(), ligand_seq[:, :Ll], ligand_mask[:, :Ll].contiguous()
+        ligand_angles = ligand_angles[:, :Ll].contiguous()
+        receptor_seq, receptor_angles = receptor_seq[:, :Lr].contiguous(), receptor_angles[:, :Lr].contiguous()
+        receptor_mask = receptor_mask[:, :Lr].contiguous()
+        if us is not None:
+            us = [u[:, :Ll] if u is not None and u.dim() >= 2 else u for u in us]
     for n, s_int in enumerate(reversed(range(T))):
         s_array = s_int * torch.ones((B, 1), device=dev)
         t_array = s_array + 1

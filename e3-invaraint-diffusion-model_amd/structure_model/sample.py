@@ -162,10 +162,23 @@ def _use_graph(x):
     return os.environ.get("E3D_SAMPLE_GRAPH") == "1"
 
 
+def trimmed_length(mask, multiple=32):
+    """Smallest multiple of ``multiple`` that covers every valid position of a [B,L] 0/1 padding mask whose valid
+    positions are a prefix (the dataset layout, dataset.py:119-132); L itself if any row is not a prefix mask."""
+    L = mask.shape[1]
+    lengths = mask.sum(dim=1)
+    prefix = (mask[:, :-1] >= mask[:, 1:]).all() if L > 1 else torch.tensor(True)
+    longest = int(lengths.max().item())
+    if not bool(prefix):
+        return L
+    return max(multiple, min(L, -(-longest // multiple) * multiple))
+
+
 @torch.no_grad()
 def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_seq, receptor_mask,
                   receptor_angle, total_timesteps: int, betas, disable_pbar: bool = False,
-                  noises=None, return_device: bool = False, step: int = None, use_graph: bool = None) -> torch.Tensor:
+                  noises=None, return_device: bool = False, step: int = None, use_graph: bool = None,
+                  trim_padding: bool = False) -> torch.Tensor:
     """Full reverse chain; returns [T/STEP, B, L, n_ft] (on the host like the reference,
     sample.py:101-144, unless ``return_device``).  ``noises`` [T/STEP,B,L,n_ft] injects the draws.
     ``use_graph``: replay one captured HIP graph per step (opt-in, also E3D_SAMPLE_GRAPH=1 -- see
@@ -174,6 +187,21 @@ def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_se
     tab = _tables(betas)
     order = list(reversed(range(0, total_timesteps, step)))
     x = ligand_angle_noise.contiguous().float()
+    full_traj = None
+    if trim_padding:
+        # Padding positions cannot influence valid ones (their keys carry the -10000 bias, whose softmax weight
+        # underflows to exactly 0.0f; every other op is row-wise), so the chain only needs the rows up to the longest
+        # ligand / pocket of the batch, rounded up to the 32-row attention tile.  BioLiP ligands are 5-30 residues
+        # in a 64-256 row frame: the decoder then runs on 1/8 of the rows.  Valid positions are unchanged; trimmed
+        # positions come back as 0 (the reference's values there are never used: sample.py:243 slices them off).
+        Ll, Lr = trimmed_length(ligand_mask), trimmed_length(receptor_mask)
+        if Ll < x.shape[1] or Lr < receptor_mask.shape[1]:
+            full_traj = torch.zeros((len(order),) + tuple(x.shape), device=x.device, dtype=torch.float32)
+            x, ligand_mask = x[:, :Ll].contiguous(), ligand_mask[:, :Ll].contiguous()
+            receptor_seq, receptor_mask = receptor_seq[:, :Lr].contiguous(), receptor_mask[:, :Lr].contiguous()
+            receptor_angle = receptor_angle[:, :Lr].contiguous()
+            if noises is not None:
+                noises = noises[:, :, :Ll]
     cache = model.encode_receptor(receptor_seq, receptor_angle, receptor_mask)
     traj = torch.empty((len(order),) + tuple(x.shape), device=x.device, dtype=torch.float32)
     graphed = None
@@ -191,6 +219,9 @@ def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_se
         else:
             x = _reverse_step(model, ligand_mask, x, None, None, None, i, tab,
                               None if noises is None else noises[n], cache, traj[n], wrap=True)
+    if full_traj is not None:
+        full_traj[:, :, :traj.shape[2]] = traj
+        traj = full_traj
     return traj if return_device else traj.cpu()
 
 
@@ -247,7 +278,7 @@ def sample(model, test_angle_ds, all_batches: bool = False):
             model=model, ligand_mask=lm.to(DEVICE), ligand_angle_noise=x_T.to(DEVICE),
             receptor_seq=receptor_seq[idx].to(DEVICE), receptor_mask=receptor_mask[idx].to(DEVICE),
             receptor_angle=receptor_angle[idx].to(DEVICE), total_timesteps=test_angle_ds.timesteps,
-            betas=test_angle_ds.alpha_beta_terms["betas"])
+            betas=test_angle_ds.alpha_beta_terms["betas"], trim_padding=True)   # sliced to l_i right below
         retval.extend(sampled[:, i, :l, :].numpy() for i, l in enumerate(lengths))
         if not all_batches:
             break

@@ -140,3 +140,28 @@ def test_joint_structure_to_sequence_pipeline_on_device(pkg, hip):
     assert len(pred_seq) == B and all(len(p) == int(n) for p, n in zip(pred_seq, pk["ligand_length"]))
     assert all(0.0 <= r <= 1.0 for r in rates) and set("".join(pred_seq)) <= set("ACDEFGHIKLMNPQRSTVWY")
     assert seq_sample.CONFIG["timesteps"] == 50          # the per-call override did not leak
+
+
+@pytest.mark.gpu
+def test_trimmed_sequence_chain_gives_the_same_sequences(pkg, hip):
+    """sequence_model/sample.py::denoise(trim_padding=True): deterministic (argmax) chain on the frame trimmed to
+    the longest ligand / pocket against the padded frame -- identical predicted sequences."""
+    from helpers import seeded_state_dict, synthetic_pockets
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    from e3diff_amd.sequence_model.sample import denoise, generate_discrete_noise
+    from e3diff_amd.sequence_model.utils import DiscreteUniformTransition, PredefinedNoiseScheduleDiscrete
+    L, B, T = 128, 4, 6
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=L)
+    enc, dec = BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True)
+    qmodel = PeptideDiff(enc, dec, feature_names=list("ACDEFGHIKLMNPQRSTVWY"), loss_func=torch.nn.CrossEntropyLoss(),
+                         noise_schedule="cosine", timesteps=T)
+    qmodel.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in qmodel.state_dict().items()}, seed=2))
+    qmodel = qmodel.eval().cuda()
+    pk = dict(synthetic_pockets(B, L, seed=8, with_ligand_seq=True, rec_range=(20, 60)), structure_ids=None)
+    sched = PredefinedNoiseScheduleDiscrete("cosine", T).cuda()
+    torch.manual_seed(4)
+    x_T = generate_discrete_noise(B, L, 20, "cuda")
+    full = denoise(pk, qmodel, sched, DiscreteUniformTransition(20), False, x_T=x_T, timesteps=T)
+    trim = denoise(pk, qmodel, sched, DiscreteUniformTransition(20), False, x_T=x_T, timesteps=T, trim_padding=True)
+    assert trim[2] == full[2] and trim[1] == full[1] and trim[3] == full[3]

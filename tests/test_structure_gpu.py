@@ -227,3 +227,37 @@ def test_hip_graph_replay_of_the_reverse_step_is_bit_identical(pkg, hip):
     # and the self-drawing graph (production path) produces a finite, wrapped chain
     free = S.p_sample_loop(*args, return_device=True, step=1, use_graph=True)
     assert torch.isfinite(free).all() and free.abs().max() <= 3.1416
+
+
+def test_trimmed_sampling_chain_equals_the_padded_one_on_valid_positions(pkg, hip):
+    """p_sample_loop(trim_padding=True): the chain on the rows up to the longest ligand / pocket of the batch
+    (32-row granularity) against the full padded frame, same injected noise."""
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model import sample as S
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as M
+    from e3diff_amd.structure_model.utils import CosineTables, modulo_with_wrapped_range
+    B, L, T = 3, 128, 6
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=2,
+             max_position_embeddings=L, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(0)
+    model = M(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True),
+              feature_names=list("abcdefgh"), loss_func=[M.diheral_loss_func] * 8).eval().to("cuda:0")
+    pk = {k: v.to("cuda:0") for k, v in synthetic_pockets(B, L, seed=3, rec_range=(20, 70)).items() if torch.is_tensor(v)}
+    assert S.trimmed_length(pk["ligand_attn_mask"]) == 32 and S.trimmed_length(pk["receptor_attn_mask"]) < L
+    g = torch.Generator().manual_seed(5)
+    x_T = modulo_with_wrapped_range(torch.randn(B, L, 8, generator=g)).to("cuda:0")
+    noises = torch.randn(T, B, L, 8, generator=g).to("cuda:0")
+    args = (model, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"], pk["receptor_angles"], T,
+            CosineTables(T))
+    full = S.p_sample_loop(*args, noises=noises, return_device=True, step=1)
+    trim = S.p_sample_loop(*args, noises=noises, return_device=True, step=1, trim_padding=True)
+    valid = pk["ligand_attn_mask"].bool()[None, :, :, None].expand_as(full)
+    # the same arithmetic on the same rows (different kernel variants by shape): fp32 rounding noise at most,
+    # through 6 steps of the amplifying reverse chain
+    d = modulo_with_wrapped_range((full - trim)[valid])
+    assert d.abs().max() < 2e-4, d.abs().max()
+    assert (trim[:, :, 32:] == 0).all()
+    # a mask that is not a prefix keeps the full frame
+    holes = pk["ligand_attn_mask"].clone()
+    holes[0, 100] = 1.0
+    assert S.trimmed_length(holes) == L

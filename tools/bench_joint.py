@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--t-structure", type=int, default=1000)
     ap.add_argument("--t-sequence", type=int, default=50)
+    ap.add_argument("--trim", action="store_true", help="trim_padding=True in both chains (frame of the longest ligand / pocket)")
     a = ap.parse_args()
     B, L = a.batch, a.seq_len
     from e3diff_amd.structure_model import sample as SS
@@ -63,15 +64,16 @@ def main():
                      dpk["receptor_angles"], 4, CosineTables(4), disable_pbar=True, return_device=True, step=1)
     t0 = sync()
     traj = SS.p_sample_loop(smodel, dpk["ligand_attn_mask"], x_T, dpk["receptor_seq"], dpk["receptor_attn_mask"],
-                            dpk["receptor_angles"], a.t_structure, tab, disable_pbar=True, return_device=True, step=1)
+                            dpk["receptor_angles"], a.t_structure, tab, disable_pbar=True, return_device=True, step=1,
+                            trim_padding=a.trim)
     t1 = sync()
     angles = QJ.angles_from_trajectory(traj, dpk["ligand_attn_mask"])
     schedule = PredefinedNoiseScheduleDiscrete("cosine", a.t_sequence).to(DEV)
-    ids, true_s, pred_s, rec = QJ.denoise(pk, angles, qmodel, schedule, DiscreteUniformTransition(20), True,
+    ids, true_s, pred_s, rec = QJ.denoise(pk, angles, qmodel, schedule, DiscreteUniformTransition(20), True, trim_padding=a.trim,
                                           timesteps=a.t_sequence)
     t2 = sync()
     n1, n2 = a.t_structure, a.t_sequence
-    print(f"joint sampling, {B} pockets x L={L} on one GPU: structure {n1} steps {t1 - t0:.2f} s "
+    print(f"joint sampling{' (trimmed frames)' if a.trim else ''}, {B} pockets x L={L} on one GPU: structure {n1} steps {t1 - t0:.2f} s "
           f"({B * n1 / (t1 - t0):.0f} pocket-steps/s, {1e3 * (t1 - t0) / n1:.2f} ms/step, encoder cached), "
           f"sequence {n2} steps {t2 - t1:.2f} s ({B * n2 / (t2 - t1):.0f} pocket-steps/s, {1e3 * (t2 - t1) / n2:.2f} ms/step); "
           f"total {t2 - t0:.2f} s = {B / (t2 - t0):.1f} pockets/s; trajectory kept on device "
