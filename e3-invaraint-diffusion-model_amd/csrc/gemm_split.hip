@@ -699,7 +699,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     }
     const int tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
     // (measured: a win only for very small grids -- single-pocket sampling; at M = 4096 the 256-row form is 25 % faster)
-    if (NS == 2 && (wm_pref == 2 || (wm_pref == 0 && tiles256 < 32 && !A_KMAJ && !B_KMAJ)))
+    if (NS == 2 && (wm_pref == 2 || (wm_pref == 0 && tiles256 < 128 && !A_KMAJ && !B_KMAJ)))
         return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
     return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
