@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as TF
 
-from helpers import FULL_SEQ, FULL_STRUCT, rel_err, seeded_state_dict, synthetic_pockets
+from helpers import rel_err, seeded_state_dict, synthetic_pockets
 from oracle import bert as obert, sequence as oseq, structure as ostr
 
 pytestmark = pytest.mark.gpu

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, seeded_state_dict, synthetic_pockets
+from helpers import GOLDEN, synthetic_pockets
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -36,7 +36,6 @@ def main():
     from e3diff_amd.structure_model import sample as SS
     from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as SM
     from e3diff_amd.structure_model.utils import CosineTables, modulo_with_wrapped_range
-    from e3diff_amd.sequence_model import sample as QS
     from e3diff_amd.sequence_model import sample_by_generated_angles as QJ
     from e3diff_amd.sequence_model.model import PeptideDiff
     from e3diff_amd.sequence_model.utils import DiscreteUniformTransition, PredefinedNoiseScheduleDiscrete
