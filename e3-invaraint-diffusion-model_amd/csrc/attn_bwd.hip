@@ -334,13 +334,14 @@ extern "C" int64_t e3d_relkey_attn_bwd_workspace_floats(int B, int nh, int Lq, i
     return 2 * pm + part;
 }
 
-extern "C" int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
-                                        int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb,
-                                        int P, const float* key_mask, const float* out, const float* lse,
-                                        const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs, float* dk,
-                                        int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs, int64_t dv_rs,
-                                        float* d_dist_emb, float* workspace, int B, int nh, int Lq, int Lk, float drop_p,
-                                        uint64_t drop_seed, void* stream) {
+extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                      int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb,
+                                      int P, const float* key_mask, const float* out, const float* lse,
+                                      const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs, float* dk,
+                                      int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs, int64_t dv_rs,
+                                      float* d_dist_emb, float* workspace, int B, int nh, int Lq, int Lk, int terms,
+                                      float drop_p, uint64_t drop_seed, void* stream) {
+    E3D_REQUIRE(terms == 0 || terms == 3 || terms == 6, "attn_bwd: terms must be 0 (fp32 MFMA), 3 or 6 (got %d)", terms);
     E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_bwd: drop_p=%g outside [0, 1)", (double)drop_p);
     const E3dDrop drop = e3d_drop_make(drop_p, drop_seed);
     E3D_REQUIRE(q && k && v && out && lse && dout && dq && dk && dv && workspace, "attn_bwd: null pointer");
@@ -358,6 +359,12 @@ extern "C" int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_
     float* dSm = workspace + pm;
     float* part = workspace + 2 * pm;
     const int wpb = 4;
+    if (terms == 3) {   // bf16x3 arithmetic (attn_bwd_split.hip); 0 and 6 keep the fp32 MFMA kernels below
+        const int rc = e3d_attn_bwd_split_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse,
+                                                 dout, dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, Pm, dSm, part, B,
+                                                 nh, Lq, Lk, drop, drop_p > 0.f, s);
+        if (rc) return rc;
+    } else {
     {
         const int n_units = B * nh * q_tiles;
         const int n_blocks = (n_units + wpb - 1) / wpb;
@@ -384,6 +391,7 @@ extern "C" int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_
         int rc = e3d_launch_status("e3d_relkey_attn_bwd (dkv)");
         if (rc) return rc;
     }
+    }
     if (dist_emb) {
         hipError_t e = hipMemsetAsync(d_dist_emb, 0, (size_t)(2 * P - 1) * D * sizeof(float), s);
         E3D_REQUIRE(e == hipSuccess, "attn_bwd: memset failed: %s", hipGetErrorString(e));
@@ -401,7 +409,19 @@ extern "C" int e3d_relkey_attn_bwd(const float* q, int64_t q_bs, int64_t q_rs, c
                                    float* dq, int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs,
                                    float* dv, int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, float* workspace, int B,
                                    int nh, int Lq, int Lk, void* stream) {
-    return e3d_relkey_attn_bwd_drop(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout, dq,
-                                    dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, d_dist_emb, workspace, B, nh, Lq, Lk,
-                                    0.f, 0, stream);
+    return e3d_relkey_attn_bwd_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout, dq,
+                                  dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, d_dist_emb, workspace, B, nh, Lq, Lk, 0,
+                                  0.f, 0, stream);
+}
+
+extern "C" int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                                        int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb,
+                                        int P, const float* key_mask, const float* out, const float* lse,
+                                        const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs, float* dk,
+                                        int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs, int64_t dv_rs,
+                                        float* d_dist_emb, float* workspace, int B, int nh, int Lq, int Lk, float drop_p,
+                                        uint64_t drop_seed, void* stream) {
+    return e3d_relkey_attn_bwd_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout, dq,
+                                  dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, d_dist_emb, workspace, B, nh, Lq, Lk, 0,
+                                  drop_p, drop_seed, stream);
 }

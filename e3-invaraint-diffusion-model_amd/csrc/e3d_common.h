@@ -85,6 +85,14 @@ __device__ __forceinline__ uint64_t e3d_attn_drop_idx4(int bh, int Lq, int Lk, i
     return ((uint64_t)bh * Lq + q) * (uint64_t)((Lk + 3) >> 2) + (uint64_t)(key0 >> 2);
 }
 
+// attn_bwd_split.hip: launches A and B of the attention backward in bf16x3 arithmetic (internal)
+int e3d_attn_bwd_split_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
+                              const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
+                              const float* key_mask, const float* out, const float* lse, const float* dout, float* dq,
+                              int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs, float* dv,
+                              int64_t dv_bs, int64_t dv_rs, float* Pm, float* dSm, float* part, int B, int nh, int Lq,
+                              int Lk, E3dDrop drop, bool dropping, hipStream_t s);
+
 // XCD-aware remap (cdna_hip_programming.md T1, bijective form): consecutive logical ids
 // land on one XCD so that workgroups sharing operands share an L2.
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "e3d_relkey_attn_bwd_drop": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
                                          _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                          _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint64, _P]),
+    "e3d_relkey_attn_bwd_ex": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
+                                       _P, _P, _P, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
+                                       _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, _P]),
     "e3d_attn_dropout_mask": (c_int, [c_int, c_int, c_int, c_int, c_float, c_uint64, _P, _P]),
     "e3d_layernorm_bwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
     "e3d_adaln_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P]),

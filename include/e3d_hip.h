@@ -221,6 +221,17 @@ int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const f
                              int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, float* workspace, int B,
                              int nh, int Lq, int Lk, float drop_p, uint64_t drop_seed, void* stream);
 
+/* The full form: ``terms`` selects the arithmetic of the backward products -- 0 = exact fp32 MFMA (what the two
+ * entry points above run), 3 = bf16x3 split operands on the bf16 MFMA (fp32 accumulation; 5x fewer matrix-pipe
+ * cycles), 6 = the fp32 MFMA kernels again (no bf16x6 backward: the fp32-grade mode stays exact). */
+int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
+                           int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
+                           const float* dist_emb, int P, const float* key_mask, const float* out,
+                           const float* lse, const float* dout, float* dq, int64_t dq_bs, int64_t dq_rs,
+                           float* dk, int64_t dk_bs, int64_t dk_rs, float* dv, int64_t dv_bs,
+                           int64_t dv_rs, float* d_dist_emb, float* workspace, int B, int nh, int Lq,
+                           int Lk, int terms, float drop_p, uint64_t drop_seed, void* stream);
+
 /* Test aid: the multipliers (0 or 1/(1-p')) the two calls above apply to P[b,h,q,key] -> out [B,nh,Lq,Lk]. */
 int e3d_attn_dropout_mask(int B, int nh, int Lq, int Lk, float p, uint64_t seed, float* out, void* stream);
 

@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")/../e3-invaraint-diffusion-model_amd/csrc"
 mkdir -p ../../lab_build/obj
 objs=""
-for s in capi gemm_f32 gemm_split attn_relkey attn_relkey_split attn_relkey_coop rowops sampler train_ops attn_bwd nerf dropout; do
+for s in capi gemm_f32 gemm_split attn_relkey attn_relkey_split attn_relkey_coop rowops sampler train_ops attn_bwd attn_bwd_split nerf dropout; do
   if [ $s = gemm_split ] || [ $s = attn_relkey_coop ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 ${LAB_DEFS:--DE3D_STAMPS} -c $s.hip -o ../../lab_build/obj/$s.o
     objs="$objs ../../lab_build/obj/$s.o"
