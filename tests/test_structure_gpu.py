@@ -261,3 +261,45 @@ def test_trimmed_sampling_chain_equals_the_padded_one_on_valid_positions(pkg, hi
     holes = pk["ligand_attn_mask"].clone()
     holes[0, 100] = 1.0
     assert S.trimmed_length(holes) == L
+
+
+def test_full_bench_size_properties(pkg, hip):
+    """BASELINE configs[2] size -- 256 x 256-residue pockets, 12+12 layers x 768: the shape bench.py times, served by
+    the persistent 256x256 GEMM and the 8-wave cooperative attention kernel.  Too large for the CPU oracle as a
+    whole, so: (1) the first items of the full batch against the same items run alone (general GEMM kernel, other
+    launch geometry) AND that small run against the oracle; (2) padding invariance; (3) dense vs padding-skip key
+    sweep bit-identical; (4) the sampler's cached-encoder path bit-identical."""
+    B, L, NS = 256, 256, 2
+    model, sd = build(pkg, FULL_STRUCT, L, seed=21)
+    pk = synthetic_pockets(B, L, seed=77)
+    d = to_dev(pk)
+    g = torch.Generator().manual_seed(5)
+    x_t = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=g))
+    t = torch.full((B,), 731)
+    args = (d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+    with torch.no_grad():
+        full = model(t.to(DEV), x_t.to(DEV), *args)
+        assert full.shape == (B, L, 8) and torch.isfinite(full).all()
+        # (1) cross-geometry agreement and oracle parity on the first NS items
+        small = model(t[:NS].to(DEV), x_t[:NS].to(DEV), *(a[:NS].contiguous() for a in args))
+        assert rel_err(full[:NS], small) < 2e-5
+        want = ostr.forward(sd, {"num_heads": 12, "max_pos": L}, t[:NS], x_t[:NS], pk["ligand_attn_mask"][:NS],
+                            pk["receptor_seq"][:NS], pk["receptor_angles"][:NS], pk["receptor_attn_mask"][:NS])
+        assert rel_err(small, want) < TOL and rel_err(full[:NS], want) < TOL
+        # (2) values at padded positions never reach real positions
+        ra = d["receptor_angles"] + (1 - d["receptor_attn_mask"])[..., None] * 3.0
+        xt2 = x_t.to(DEV) + (1 - d["ligand_attn_mask"])[..., None] * 3.0
+        moved = model(t.to(DEV), xt2, d["ligand_attn_mask"], d["receptor_seq"], ra, d["receptor_attn_mask"])
+        m = d["ligand_attn_mask"].bool()
+        assert rel_err(moved[m], full[m]) < 1e-5
+        # (3) the attention sweep that stops after the last valid key tile is the dense sweep, bit for bit
+        lib = pkg.hip.lib()
+        prev = lib.e3d_attn_skip_padded_tiles(0)
+        try:
+            dense = model(t.to(DEV), x_t.to(DEV), *args)
+        finally:
+            lib.e3d_attn_skip_padded_tiles(prev)
+        assert torch.equal(dense, full)
+        # (4) pocket encoder + cross K/V computed once (the sampler's loop)
+        cache = model.encode_receptor(d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+        assert torch.equal(model.decode(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], cache), full)
