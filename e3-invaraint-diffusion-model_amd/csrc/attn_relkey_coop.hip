@@ -409,7 +409,7 @@ int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         void* e_scratch, hipStream_t s) {
+                         void* e_scratch, int e_ready, hipStream_t s) {
     const int q_tiles = (Lq + 31) / 32;
     static int w_max = 0;   // E3D_ATTN_W caps the waves per workgroup (experiments)
     if (!w_max) {
@@ -432,7 +432,8 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
             return (int)e;
         }
     }
-    hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
+    if (!(e_ready && e_scratch))   // e_ready: the caller kept the planes of this (dist_emb, Lk) from an earlier call
+        hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
     const int rc = launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh,
                                     Lq, Lk, q_tiles, skip, s);
     if (!e_scratch) (void)hipFreeAsync(planes, s);
@@ -444,5 +445,13 @@ extern "C" int e3d_debug_read_attn_stamps(long long* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(e3d_attn_stamps), sizeof(long long) * 16 * 8);
 }
 #endif
+
+// the pre-pass alone: fragment-order planes of dist_emb for key length Lk into ``scratch``
+int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, hipStream_t s) {
+    const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
+    hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
+                       reinterpret_cast<bf16x8*>(scratch), P, J0, n_items);
+    return e3d_launch_status("e3d_relkey_attn_fwd_split (distance-table planes)");
+}
 
 extern "C" int64_t e3d_attn_scratch_bytes(int Lk) { return (int64_t)2 * ((Lk + 31) / 32) * 512 * 16; }

@@ -334,7 +334,7 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
                                             int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                             const float* dist_emb, int P, const float* key_mask, float* out,
                                             float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
-                                            uint64_t drop_seed, void* e_scratch, void* stream) {
+                                            uint64_t drop_seed, void* e_scratch, int e_scratch_ready, void* stream) {
     E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_split: drop_p=%g outside [0, 1)", (double)drop_p);
     E3D_REQUIRE(q && k && v && out, "attn_split: null pointer");
     E3D_REQUIRE(B > 0 && nh > 0 && Lq > 0 && Lk > 0, "attn_split: bad shape B=%d nh=%d Lq=%d Lk=%d", B, nh, Lq, Lk);
@@ -351,6 +351,12 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     }
     E3D_REQUIRE((int64_t)B * nh * ((Lq + 31) / 32) < (1ll << 30), "attn_split: too many tiles");
     hipStream_t s = (hipStream_t)stream;
+    if (dist_emb && e_scratch && !e_scratch_ready) {
+        // whichever kernel serves this call, a scratch handed in is valid afterwards (callers cache it)
+        const int rc = e3d_attn_fill_planes(dist_emb, P, Lk, e_scratch, s);
+        if (rc) return rc;
+        e_scratch_ready = 1;
+    }
     if (drop_p > 0.f) {   // training with attention-probability dropout: per-wave kernel
         const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
         if (terms == 3)
@@ -365,7 +371,7 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     // two-wave groups (q_tiles % 4 != 0) measured slower than the per-wave kernel: too little sharing per barrier
     if (terms == 3 && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, g_skip_padded, e_scratch, s);
+                                    Lq, Lk, g_skip_padded, e_scratch, e_scratch_ready, s);
     if (terms == 3)
         return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
     return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
@@ -376,7 +382,7 @@ extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q
                                          const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
                                          int B, int nh, int Lq, int Lk, int terms, void* stream) {
     return e3d_relkey_attn_fwd_split_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B,
-                                        nh, Lq, Lk, terms, 0.f, 0, nullptr, stream);
+                                        nh, Lq, Lk, terms, 0.f, 0, nullptr, 0, stream);
 }
 
 extern "C" int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
@@ -385,5 +391,5 @@ extern "C" int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int6
                                               float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                               uint64_t drop_seed, void* stream) {
     return e3d_relkey_attn_fwd_split_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B,
-                                        nh, Lq, Lk, terms, drop_p, drop_seed, nullptr, stream);
+                                        nh, Lq, Lk, terms, drop_p, drop_seed, nullptr, 0, stream);
 }

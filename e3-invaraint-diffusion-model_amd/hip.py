@@ -40,7 +40,7 @@ _SIGNATURES = {
                                                c_uint64, _P]),
     "e3d_relkey_attn_fwd_split_ex": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                              _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float,
-                                             c_uint64, _P, _P]),
+                                             c_uint64, _P, c_int, _P]),
     "e3d_attn_scratch_bytes": (c_int64, [c_int]),
     "e3d_ddpm_step_wrap_table": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int64, _P]),
     "e3d_relkey_attn_bwd_drop": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,

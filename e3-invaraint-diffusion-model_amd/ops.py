@@ -148,11 +148,22 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         else:
             # scratch for the bf16 planes of dist_emb (cooperative kernel): a torch allocation keeps the call
             # free of stream-ordered hipMallocAsync, so the launch sequence can be captured into a HIP graph
-            scratch = None
+            scratch, ready = None, 0
             if dist_emb is not None:
-                scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
+                # inference (grad disabled): the planes are kept across calls, keyed by the tensor's version / storage
+                infer = not torch.is_grad_enabled()
+                ent = getattr(dist_emb, "_e3d_planes", None) if infer else None
+                if ent is not None and ent[0] == (dist_emb._version, dist_emb.data_ptr(), Lk):
+                    scratch, ready = ent[1], 1
+                else:
+                    scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
+                    if infer and not torch.cuda.is_current_stream_capturing():
+                        try:
+                            dist_emb._e3d_planes = ((dist_emb._version, dist_emb.data_ptr(), Lk), scratch)
+                        except AttributeError:
+                            pass
             p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)
-            hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), _stream()),
+            hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), ready, _stream()),
                       "e3d_relkey_attn_fwd_split_ex")
     return (out, lse) if want_lse else out
 

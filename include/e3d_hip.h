@@ -204,13 +204,15 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
 /* The full form of the two above: ``e_scratch`` (device, >= e3d_attn_scratch_bytes(Lk) bytes, 16-byte
  * aligned, or NULL) receives the fragment-order bf16 hi/lo planes of dist_emb that the cooperative kernel
  * reads; with NULL the library takes a stream-ordered allocation (hipMallocAsync), which callers that
- * capture the stream into a hipGraph should avoid. */
+ * capture the stream into a hipGraph should avoid.  ``e_scratch_ready`` != 0: the scratch still holds the planes
+ * written by an earlier call with the same dist_emb values and Lk (constant weights: inference) -- the 5-us
+ * pre-pass is skipped. */
 int64_t e3d_attn_scratch_bytes(int Lk);
 int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                  int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                  const float* dist_emb, int P, const float* key_mask, float* out,
                                  float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
-                                 uint64_t drop_seed, void* e_scratch, void* stream);
+                                 uint64_t drop_seed, void* e_scratch, int e_scratch_ready, void* stream);
 
 /* e3d_relkey_attn_bwd for a forward that used (drop_p, drop_seed). */
 int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,

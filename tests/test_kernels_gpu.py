@@ -322,3 +322,23 @@ def test_discrete_q_sample(pkg, hip):
     clear = ((cdf - (u.reshape(-1, 1) * cdf[:, -1:])).abs().min(-1).values > 1e-6) | (prob.sum(-1) == 0)
     assert torch.equal(got.reshape(-1)[clear], want.reshape(-1)[clear])
     assert bool((got[:, 10:] == 0).all())
+
+
+def test_distance_table_planes_cache_follows_weight_updates(pkg, hip):
+    """ops.attention keeps the bf16 planes of dist_emb across inference calls (keyed by the tensor's version and
+    storage): an in-place update of the table must be seen by the next call."""
+    ops = pkg.ops
+    B, nh, L, H = 2, 2, 128, 128
+    qkv = torch.randn(B * L, 3 * H, generator=g(1)).to(DEV)
+    E = torch.randn(2 * L - 1, 64, generator=g(2)).to(DEV)
+    mask = torch.ones(B, L, device=DEV)
+    call = lambda e: ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,  # noqa: E731
+                                   dist_emb=e, max_pos=L, mode="bf16x3")
+    with torch.no_grad():
+        out1 = call(E)
+        assert getattr(E, "_e3d_planes", None) is not None
+        assert torch.equal(call(E), out1)            # served from the cached planes
+        E.mul_(-1.5)                                  # version bump
+        out2 = call(E)
+        fresh = call(E.clone())                       # a tensor without cache entry
+    assert torch.equal(out2, fresh) and not torch.equal(out2, out1)
