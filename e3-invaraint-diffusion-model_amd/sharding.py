@@ -72,17 +72,20 @@ def mean_over_ranks(value):
 
 
 class GradientAverager:
-    """Bucketed all-reduce(sum)/world of parameter gradients.
+    """Bucketed all-reduce(sum)/world of parameter gradients, overlapped with the backward pass
+    (``prepare`` before ``backward``, ``average`` after it).
 
     The bucket plan is STATIC (built from the parameter list, identical on every rank), and a
     parameter whose grad is None contributes zeros -- the sequence model owns parameters that its
     forward never touches (``receptor_feature_emb``, reference sequence_model/model.py:176 vs 221),
     which would desynchronise a plan built from the non-None grads."""
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=True):
         self.params = [p for p in params if p.requires_grad]
+        # buckets follow the REVERSE parameter order: gradients become ready roughly back to front, so the
+        # first buckets to complete are the first to go on the wire while the backward pass continues
         self.buckets, cur, size = [], [], 0
-        for p in self.params:
+        for p in reversed(self.params):
             cur.append(p)
             size += p.numel() * 4
             if size >= bucket_bytes:
@@ -90,18 +93,69 @@ class GradientAverager:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        self._flat = {}
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._flat, self._handles, self._pending, self._bound = {}, {}, None, False
+        if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    @staticmethod
+    def _active():
+        return dist.is_initialized() and dist.get_world_size() > 1
+
+    def _buffer(self, i):
+        bucket = self.buckets[i]
+        flat = self._flat.get(i)
+        if flat is None or flat.device != bucket[0].device:
+            flat = self._flat[i] = torch.empty(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+        return flat
+
+    def prepare(self):
+        """Call after ``zero_grad`` and before ``backward``: every ``.grad`` becomes a zeroed VIEW of its
+        bucket's flat buffer (autograd then accumulates in place: no flatten / unflatten copies), and a bucket
+        goes on the wire -- asynchronously, overlapping the rest of the backward pass -- the moment its last
+        gradient has been accumulated.  Without this call ``average`` still works (copying path)."""
+        if not self._active():
+            return
+        for i, bucket in enumerate(self.buckets):
+            flat = self._buffer(i)
+            flat.zero_()
+            off = 0
+            for p in bucket:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self._pending = [len(b) for b in self.buckets]
+        self._handles, self._bound = {}, True
+
+    def _on_grad(self, p):
+        if not self._bound:
+            return
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._launch(i)
+
+    def _launch(self, i):
+        self._handles[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True)
 
     def average(self):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+        if not self._active():
             return
         world = dist.get_world_size()
+        if self._bound:
+            # buckets that hold a never-used parameter (its hook never fires) go last, in index order: the
+            # set and the order are the same on every rank because the autograd graph is
+            for i in range(len(self.buckets)):
+                if i not in self._handles:
+                    self._launch(i)
+            for i in range(len(self.buckets)):
+                self._handles[i].wait()
+                self._flat[i].div_(world)
+            self._bound = False
+            return
         handles = []
         for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            flat = self._flat.get(i)
-            if flat is None or flat.device != bucket[0].device:
-                flat = self._flat[i] = torch.empty(n, dtype=torch.float32, device=bucket[0].device)
+            flat = self._buffer(i)
             off = 0
             for p in bucket:
                 dst = flat[off:off + p.numel()]

@@ -59,6 +59,7 @@ def fit(model, train_loader, val_loader=None, *, max_epochs, min_epochs=0, gradi
             batch = move_batch(batch, device)
             loss = model.training_step(batch, batch_idx)
             optim.zero_grad(set_to_none=True)
+            averager.prepare()                       # grads as views of the all-reduce buckets (no-op for one process)
             loss.backward()
             averager.average()                       # RCCL all-reduce (no-op for one process)
             if gradient_clip:

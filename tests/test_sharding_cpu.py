@@ -44,13 +44,25 @@ def _worker(rank, world, port, q):
     x = torch.full((2, 5), float(rank + 1))
     model["b"](model["a"](x)).sum().backward()
     local_grad = model["a"].weight.grad.clone()
-    avg = S.GradientAverager(model.parameters(), bucket_bytes=64)   # tiny buckets: several collectives
+    avg = S.GradientAverager(model.parameters(), bucket_bytes=32)   # tiny buckets: several collectives
     assert len(avg.buckets) > 2
     avg.average()
     both = [torch.zeros_like(local_grad) for _ in range(world)]
     torch.distributed.all_gather(both, local_grad)
     assert torch.allclose(model["a"].weight.grad, sum(both) / world)
     assert model["unused"].weight.grad is not None and float(model["unused"].weight.grad.abs().sum()) == 0.0
+    # ---- the overlapped path: grads are views of the buckets, collectives start from the autograd hooks
+    for p in model.parameters():
+        p.grad = None
+    avg.prepare()
+    model["b"](model["a"](x)).sum().backward()
+    launched_early = len(avg._handles)
+    assert launched_early >= 1                       # at least one bucket went out before average()
+    avg.average()
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
+    assert float(model["unused"].weight.grad.abs().sum()) == 0.0
+    views = [p.grad.untyped_storage().data_ptr() for p in model.parameters()]
+    assert len(set(views)) <= len(avg.buckets)       # every grad lives inside a bucket buffer
     w0 = [torch.zeros_like(model["a"].weight) for _ in range(world)]
     torch.distributed.all_gather(w0, model["a"].weight.data)
     assert torch.equal(w0[0], w0[1])
