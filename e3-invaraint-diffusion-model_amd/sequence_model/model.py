@@ -16,6 +16,7 @@ from torch.nn import functional as F
 from .. import bert, ops
 from ..blocks import (BertEmbeddings, GaussianFourierProjection, Predictor, SELayer, flat2d,
                       require_gpu)
+from ..training import adamw
 from .utils import BlosumTransition, PredefinedNoiseScheduleDiscrete, elbo_loss
 
 AA_VOCAB = "ACDEFGHIKLMNPQRSTVWY"
@@ -143,7 +144,7 @@ class PeptideDiff(ConditionalBertForDiffusionBase):
 
     def configure_optimizers(self):
         """AdamW + optional schedule (reference model.py:405-450); LinearWarmup counts epochs."""
-        optim = torch.optim.AdamW(self.parameters(), lr=self.lr, weight_decay=self.l2_lambda)
+        optim = adamw(self.parameters(), lr=self.lr, weight_decay=self.l2_lambda)
         retval = {"optimizer": optim}
         if self.lr_scheduler == "OneCycleLR":
             retval["lr_scheduler"] = {

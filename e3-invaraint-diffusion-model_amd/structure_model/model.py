@@ -12,6 +12,7 @@ from torch import nn
 from .. import bert
 from ..blocks import (BertEmbeddings, GaussianFourierProjection, Predictor, SELayer, flat2d,
                       require_gpu)
+from ..training import adamw
 from .utils import radian_l1_loss, radian_smooth_l1_loss
 
 
@@ -127,7 +128,7 @@ class ConditionalBertForDiffusion(ConditionalBertForDiffusionBase):
     def configure_optimizers(self):
         """AdamW(lr, weight_decay=l2_lambda) + optional schedule (reference model.py:361-403).
         LinearWarmup counts EPOCHS (warm-up = 10 % of ``epochs``), as the reference does."""
-        optim = torch.optim.AdamW(self.parameters(), lr=self.learning_rate, weight_decay=self.l2_lambda)
+        optim = adamw(self.parameters(), lr=self.learning_rate, weight_decay=self.l2_lambda)
         retval = {"optimizer": optim}
         if self.lr_scheduler == "OneCycleLR":
             retval["lr_scheduler"] = {

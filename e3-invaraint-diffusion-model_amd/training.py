@@ -6,9 +6,24 @@ and -- new relative to the single-GPU reference -- data-parallel gradient averag
 launched with one process per GPU (``torchrun``).
 """
 import math
+import os
 import time
 
 import torch
+
+
+def adamw(params, lr, weight_decay):
+    """torch.optim.AdamW as the reference builds it (structure_model/model.py:361-366), with the single-kernel
+    ``fused`` update when every parameter lives on the GPU (the default multi-tensor path is ~10 passes over the
+    146 M parameters, ~4 ms of a 45-ms step); E3D_FUSED_ADAMW=0 keeps torch's default."""
+    params = list(params)
+    fused = os.environ.get("E3D_FUSED_ADAMW", "1") == "1" and params and all(p.is_cuda for p in params)
+    try:
+        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True) if fused else \
+            torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+    except (TypeError, RuntimeError):
+        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
+
 
 from . import sharding
 
