@@ -277,16 +277,23 @@ def main():
                       "TFLOPs": 2.0 * k[0] * k[1] * k[2] / (sum(v) / len(v) * 1e-3) / 1e12} for k, v in by_shape.items()),
                     key=lambda d: -d["avg_launch_ms"] * d["launches_per_step"])
 
+    # the dominant kernel SYMBOL: the plain-epilogue (bias, no activation) launches of the large-M GEMM -- in the
+    # default mode gemm_split256p_kernel<0>, whose per-kernel average in a rocprofv3 --stats summary of this command
+    # is directly comparable with avg_launch_ms below
+    dom = [(ev0.elapsed_time(ev1), m) for n, ev0, ev1, m in trace
+           if n == "gemm" and (len(m) < 4 or m[3] == 0) and m[0] % 256 == 0 and m[1] % 256 == 0
+           and (m[0] // 256) * (m[1] // 256) >= 256]
+    dom_ms = sum(t for t, _ in dom) / max(1, len(dom))
+    dom_flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in dom) / max(1, len(dom))
+    dom_bytes = sum(4.0 * (m[0] * m[2] + m[1] * m[2] + m[0] * m[1] + m[1]) for _, m in dom) / max(1, len(dom))
+
     if rank == 0:
-        traffic = None
+        traffic = gemm_traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             tdict = json.load(open(tj))
             traffic = tdict.get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
-            top = shapes[0]
-            gemm_traffic = tdict.get(f"gemm_{top['M']}x{top['N']}x{top['K']}_hbm_bytes_per_launch")
-        else:
-            top, gemm_traffic = shapes[0], None
+            gemm_traffic = tdict.get(f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch")
         a_tf = attn_flops(B, L) / (attn_ms * 1e-3) / 1e12
         gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.gemm_mode]
         a_gb = attn_bytes(B, L) / (attn_ms * 1e-3) / 1e9
@@ -331,17 +338,19 @@ def main():
                 "algorithmic_TFLOPs": a_tf, "mfma_frac": a_tf / gemm_peak,
                 "hbm_algorithmic_GBps": a_gb, "hbm_frac": a_gb / PEAK_HBM_GBPS})(
                     attn_flops(B, L) / (gemm_peak * 1e12) * 1e3, attn_bytes(B, L) / (PEAK_HBM_GBPS * 1e9) * 1e3),
-            # the dominant kernel (~2/3 of the step): the GEMM, priced on its most time-consuming shape.  flops per
-            # launch = 2MNK; peak = the dense bf16 MFMA rate / cross products per fp32 product
-            "roofline": {"kernel": ("gemm_split256p_kernel (e3d_gemm_bias_act_f32_split)" if args.gemm_mode == "bf16x3" else
-                                    f"GEMM kernel of mode {args.gemm_mode}") + f", M={top['M']} N={top['N']} K={top['K']}",
-                         "bound": "mfma", "achieved": top["TFLOPs"], "peak": gemm_peak, "unit": "TFLOP/s",
-                         "frac": top["TFLOPs"] / gemm_peak, "traffic": gemm_traffic,
-                         "avg_launch_ms": top["avg_launch_ms"], "launches_per_step": top["launches_per_step"],
-                         "algorithmic_bytes_per_launch": 4.0 * (top["M"] * top["K"] + top["N"] * top["K"] +
-                                                               top["M"] * top["N"] + top["N"]),
-                         "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes; "
-                                      "traffic = HBM bytes per launch from the PMC passes in profiles/traffic.json"},
+            # the dominant kernel (~56 % of the step's kernel time): all its launches of one step.  flops per launch =
+            # 2MNK, bytes per launch = 4(MK + NK + MN + N), averaged over those launches; peak = the
+            # dense bf16 MFMA rate / cross products per fp32 product
+            "roofline": {"kernel": ("gemm_split256p_kernel<ACT_NONE> (e3d_gemm_bias_act_f32_split), " if args.gemm_mode == "bf16x3"
+                                    else f"large-M GEMM kernel of mode {args.gemm_mode}, ") +
+                                   f"all {len(dom)} launches of one step (M={B * L}; N, K in gemm_shapes)",
+                         "bound": "mfma", "achieved": dom_flops / (dom_ms * 1e-3) / 1e12, "peak": gemm_peak, "unit": "TFLOP/s",
+                         "frac": dom_flops / (dom_ms * 1e-3) / 1e12 / gemm_peak, "traffic": gemm_traffic,
+                         "avg_launch_ms": dom_ms, "launches_per_step": len(dom),
+                         "algorithmic_flops_per_launch": dom_flops, "algorithmic_bytes_per_launch": dom_bytes,
+                         "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes; traffic = HBM "
+                                      "bytes per launch (average over the same launches) from the PMC passes in "
+                                      "profiles/traffic.json"},
             "gemm_shapes": shapes,
             "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",
                               "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,

@@ -75,7 +75,7 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
     terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
-    with _timed("gemm", (M, N, K)):
+    with _timed("gemm", (M, N, K, act)):
         if terms == 0:
             hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
                                                       out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")

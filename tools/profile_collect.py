@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turn the outputs of tools/profile_round.sh (gpurun_out/prof_round/) into the committed evidence under profiles/:
+kernel-stats CSV, the bench line printed under rocprofv3, the PMC counter rows and traffic.json.
+
+    python tools/profile_collect.py <tag>        # e.g. r01_v5
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out", "prof_round")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+B, L, H = 256, 256, 768
+
+
+def counter_rows(path, needle):
+    return [r for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"]]
+
+
+def mean(rows):
+    v = [float(r["Counter_Value"]) for r in rows]
+    return sum(v) / len(v), len(v)
+
+
+def dump(rows, name):
+    cols = ["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+            "Accum_VGPR_Count", "SGPR_Count"]
+    with open(os.path.join(P, name), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=cols, extrasaction="ignore")
+        w.writeheader()
+        w.writerows(rows)
+
+
+GEMM = "gemm_split256p_kernel<0>"
+af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", "attn_coop_kernel<8, true>"), \
+    counter_rows(f"{O}/pmc_write/a_counter_collection.csv", "attn_coop_kernel<8, true>")
+gf, gw = counter_rows(f"{O}/pmc_gfetch/g_counter_collection.csv", GEMM), counter_rows(f"{O}/pmc_gwrite/g_counter_collection.csv", GEMM)
+(afm, _), (awm, _), (gfm, ng), (gwm, _) = mean(af), mean(aw), mean(gf), mean(gw)
+traffic = {
+    f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch": (2 * afm + awm) * 1024,
+    f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch": (2 * gfm + gwm) * 1024,
+    "_detail": {
+        "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes: FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes "
+                   "(no trace domains); x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)",
+        "attn": {"kernel": "attn_coop_kernel<8, true>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
+                 "WRITE_SIZE_KiB_avg": awm, "algorithmic_bytes": (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B},
+        "gemm": {"kernel": f"{GEMM}: every launch of one bench.py --headline-only step ({ng} dispatches incl. the untimed "
+                           "trace pass)", "FETCH_SIZE_KiB_raw_avg": gfm, "WRITE_SIZE_KiB_avg": gwm},
+        "command": "bash tools/profile_round.sh && python tools/profile_collect.py",
+    },
+}
+json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+dump(af, f"{tag}_attn_coop_B256_L256_pmc_fetch.csv")
+dump(aw, f"{tag}_attn_coop_B256_L256_pmc_write.csv")
+dump(gf, f"{tag}_gemm_act0_bench_step_pmc_fetch.csv")
+dump(gw, f"{tag}_gemm_act0_bench_step_pmc_write.csv")
+shutil.copy(f"{O}/stats/bench_kernel_stats.csv", os.path.join(P, f"{tag}_bench_B256_L256_kernel_stats.csv"))
+line = [ln for ln in open(f"{O}/bench_under_rocprof.log") if ln.startswith("{")][-1]
+open(os.path.join(P, f"{tag}_bench_line_under_rocprof.json"), "w").write(line)
+d = json.loads(line)
+rows = list(csv.DictReader(open(f"{O}/stats/bench_kernel_stats.csv")))
+for r in rows[:6]:
+    print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs']) / 1e3:8.1f} us {r['Percentage']:>6s} %")
+print("bench under rocprof: roofline avg_launch_ms", d["roofline"]["avg_launch_ms"], "| attention", d["roofline_attention"]["avg_launch_ms"])
+print("traffic per launch: attention", traffic[f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch"] / 1e6, "MB; GEMM",
+      traffic[f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch"] / 1e6, "MB (algorithmic", d["roofline"]["algorithmic_bytes_per_launch"] / 1e6, "MB)")

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o a -- python3 $R/tools/bench_kernels.py attn_pmc > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o a -- python3 $R/tools/bench_kernels.py attn_pmc > $O/pmc_write.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gfetch -o g -- python3 $R/tools/bench_kernels.py gemm_pmc 2304 > $O/pmc_gfetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gwrite -o g -- python3 $R/tools/bench_kernels.py gemm_pmc 2304 > $O/pmc_gwrite.log 2>&1
+# the dominant GEMM kernel symbol over one whole bench step (every launch of it, as bench.py's `roofline` prices it)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gfetch -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gwrite -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gwrite.log 2>&1
 find $O -name "*.csv" | head -20
