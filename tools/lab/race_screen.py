@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Race screen for the pipelined kernels (interleaved staging, persistent k stream, cooperative attention):
+many launches on fresh data, each checked against the exact-fp32 kernel of the same op, plus run-to-run
+bit-identity on repeated inputs.  A staging/barrier race shows up as a rare wrong tile, not as a crash."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__  # noqa: E402
+
+pkg = __graft_entry__.load_package()
+ops = pkg.ops
+dev = "cuda:0"
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+bad = 0
+for (M, N, K) in ((65536, 768, 768), (65536, 2304, 768), (32768, 1024, 1024), (16640, 1024, 768), (4096, 2304, 768), (8192, 768, 3072)):
+    worst = 0.0
+    for r in range(reps):
+        g = torch.Generator(device=dev).manual_seed(1000 * r + M % 977)
+        a = torch.randn(M, K, device=dev, generator=g)
+        w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+        b = torch.randn(N, device=dev, generator=g)
+        with torch.no_grad():
+            ref = ops.gemm(a, w, b, mode="f32")
+            out = ops.gemm(a, w, b, mode="bf16x3")
+            again = ops.gemm(a, w, b, mode="bf16x3")
+        if not torch.equal(out, again):
+            bad += 1
+            print(f"GEMM {M}x{N}x{K} rep {r}: NOT bit-identical between two launches", flush=True)
+        # block-wise: a wrong 32x32 tile cannot hide behind the global max
+        err = ((out - ref).abs().view(M // 32, 32, N // 32, 32).amax((1, 3)) / ref.abs().max()).max().item()
+        worst = max(worst, err)
+        if err > 3e-5:
+            bad += 1
+            print(f"GEMM {M}x{N}x{K} rep {r}: block error {err:.2e}", flush=True)
+    print(f"GEMM {M}x{N}x{K}: {reps} launches, worst block error vs exact fp32 kernel {worst:.2e}", flush=True)
+for (B, L) in ((256, 256), (512, 128), (64, 256)):
+    nh, H = 12, 768
+    worst = 0.0
+    for r in range(reps):
+        g = torch.Generator(device=dev).manual_seed(77 * r + L)
+        qkv = torch.randn(B * L, 3 * H, device=dev, generator=g)
+        E = torch.randn(2 * L - 1, 64, device=dev, generator=g)
+        lens = torch.randint(1, L + 1, (B,), device=dev, generator=g)
+        mask = (torch.arange(L, device=dev)[None] < lens[:, None]).float()
+        call = lambda mode: ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,  # noqa: E731
+                                          dist_emb=E, max_pos=L, mode=mode)
+        with torch.no_grad():
+            ref, out, again = call("f32"), call("bf16x3"), call("bf16x3")
+        if not torch.equal(out, again):
+            bad += 1
+            print(f"attention B={B} L={L} rep {r}: NOT bit-identical between two launches", flush=True)
+        err = ((out - ref).abs().view(B * L // 32, 32, H // 64, 64).amax((1, 3)) / ref.abs().max()).max().item()
+        worst = max(worst, err)
+        if err > 1e-4:
+            bad += 1
+            print(f"attention B={B} L={L} rep {r}: block error {err:.2e}", flush=True)
+    print(f"attention B={B} L={L}: {reps} launches, worst block error vs exact fp32 kernel {worst:.2e}", flush=True)
+print("race screen:", "CLEAN" if bad == 0 else f"{bad} PROBLEMS")
+sys.exit(1 if bad else 0)
