@@ -675,6 +675,16 @@ template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s);
 
+// smallest number of 256x256 tiles for which the persistent kernel is chosen (E3D_GEMM_P_MIN, experiments)
+int p_min() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("E3D_GEMM_P_MIN");
+        v = e ? atoi(e) : 160;   // measured: 192 tiles (M = 16384, N = 768) +9 % on the persistent kernel, 96 tiles -8 %
+    }
+    return v;
+}
+
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
            int M, int N, int K, hipStream_t s) {
@@ -683,7 +693,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         g_tile_pref = e ? atoi(e) : 4;
     }
     if (!A_KMAJ && !B_KMAJ && N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && NS == 2 && K >= 2 * BK &&
-        lda < (1 << 22) && (int64_t)(M / BT) * (N / BT) >= 256)
+        lda < (1 << 22) && (int64_t)(M / BT) * (N / BT) >= p_min())
         return launch256p<ACT>(A, lda, B, bias, out, ldc, M, N, K, s);
     if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 3 && NS == 2 &&
         (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)

@@ -38,7 +38,8 @@ def test_gemm_bias_act(pkg, hip, M, N, K, act, mode, tol):
 @pytest.mark.parametrize("M,N,K,act", [(16384, 1024, 768, 1),     # >= 256 tiles of 256x256, M % 256 == 0: persistent kernel
                                        (32768, 768, 1024, 0),     # 3 tiles per CU walk, K = 1024
                                        (16400, 1024, 768, 2),     # ragged M: interleaved-staging kernel with row clamps
-                                       (16384, 1024, 32, 0)])     # a single k-tile: the stream wraps every tile
+                                       (16384, 1024, 32, 0),      # a single k-tile: the stream wraps every tile
+                                       (16384, 768, 768, 0)])     # 192 tiles: fewer persistent workgroups than CUs
 def test_gemm_large_m_kernels(pkg, hip, M, N, K, act):
     """The large-M forward kernels (256x256 tiles; bench.py shapes are of this kind) against fp64, with a
     strided activation view (lda > K) as the packed QKV / KV consumers pass."""
