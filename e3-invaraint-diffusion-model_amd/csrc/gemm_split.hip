@@ -49,10 +49,11 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&parts)[NS]) {
 template <int ROWS, bool KMAJ, int NT = 512>
 struct Stager {
     static constexpr int NV = ROWS * 8 / NT;   // items per thread (512 threads: A 4, B 2)
-    const float* src[NV];
+    const float* src[NV];   // K-contiguous: the item's row base;  K-major: the operand base (uniform)
     int off[NV];
     int64_t ld;
-    int kbase[NV];
+    int kbase[NV];          // first k of the item inside a k-tile (K-major: wave-uniform, kept in SGPRs)
+    int roff[NV];           // K-major: the lane's element offset along the contiguous index
 
     __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int row_limit, int tid) {
         ld = ld_;
@@ -64,8 +65,12 @@ struct Stager {
             else { r = f >> 3; kg = f & 7; }             // lanes along k: 128-byte row segments
             int gr = row0 + r;
             gr = gr < row_limit ? gr : row_limit - 1;    // clamp: rows past the edge are discarded later
-            src[i] = KMAJ ? base + gr : base + (int64_t)gr * ld + kg * 4;
-            kbase[i] = kg * 4;
+            src[i] = KMAJ ? base : base + (int64_t)gr * ld + kg * 4;
+            // K-major: kg = f / ROWS is the same for the 64 lanes of a wave (ROWS is a multiple of 64); telling the
+            // compiler so keeps the k-dependent part of every address (k * ld) in scalar registers: the loads become
+            // SGPR base + one 32-bit lane offset, without per-element 64-bit VALU arithmetic or divergent branches
+            kbase[i] = KMAJ ? __builtin_amdgcn_readfirstlane(kg * 4) : kg * 4;
+            roff[i] = gr;
             off[i] = swz_off(r, kg >> 1) + (kg & 1) * 8;
         }
     }
@@ -75,8 +80,8 @@ struct Stager {
             if (KMAJ) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int k = k0 + kbase[i] + j;
-                    v[i][j] = k < K ? src[i][(int64_t)k * ld] : 0.f;   // K tail (token counts) zero-filled
+                    const int k = min(k0 + kbase[i] + j, K - 1);        // wave-uniform; the K tail is zeroed at store time
+                    v[i][j] = (src[i] + (int64_t)k * ld)[roff[i]];
                 }
             } else {
                 v[i] = *reinterpret_cast<const f32x4*>(src[i] + k0);
@@ -87,29 +92,31 @@ struct Stager {
         if (KMAJ) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + kbase[i] + j;
-                v[j] = k < K ? src[i][(int64_t)k * ld] : 0.f;
+                const int k = min(k0 + kbase[i] + j, K - 1);            // wave-uniform; the K tail is zeroed at store time
+                v[j] = (src[i] + (int64_t)k * ld)[roff[i]];
             }
         } else {
             v = *reinterpret_cast<const f32x4*>(src[i] + k0);
         }
     }
+    // ``k0`` = first k of the k-tile the registers hold: K-major items zero their reduction tail (k >= K, token
+    // counts that are not a multiple of 32) here, away from the loads, so that no load result is needed early
     template <int NS>
-    __device__ __forceinline__ void store_item(int i, const f32x4& v, unsigned char* img, int part_bytes) const {
+    __device__ __forceinline__ void store_item(int i, const f32x4& vin, unsigned char* img, int part_bytes, int k0, int K) const {
+        f32x4 v = vin;
+        if (KMAJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = k0 + kbase[i] + j < K ? v[j] : 0.f;
+        }
         bf16x4 p[NS];
         split4<NS>(v, p);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(img + s * part_bytes + off[i]) = p[s];
     }
     template <int NS>
-    __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes) const {
+    __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes, int k0, int K) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            bf16x4 p[NS];
-            split4<NS>(v[i], p);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(img + s * part_bytes + off[i]) = p[s];
-        }
+        for (int i = 0; i < NV; ++i) store_item<NS>(i, v[i], img, part_bytes, k0, K);
     }
 };
 
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
     f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
     sa.load(ra, k_begin, K);
     sb.load(rb, k_begin, K);
-    sa.template store<NS>(ra, smem_raw, A_BYTES);
-    sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES);
+    sa.template store<NS>(ra, smem_raw, A_BYTES, k_begin, K);
+    sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin, K);
     __syncthreads();
 
     const int nk = (K - k_begin + BK - 1) / BK;
@@ -203,13 +210,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
 #pragma unroll
                     for (int i = 0; i < NA_; ++i)
                         if (i * 4 / NA_ == g) {
-                            sa.template store_item<NS>(i, ra[i], nxt, A_BYTES);
+                            sa.template store_item<NS>(i, ra[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
                             sa.load_item(i, ra[i], k2, K);
                         }
 #pragma unroll
                     for (int i = 0; i < NB_; ++i)
                         if (i * 4 / NB_ == g) {
-                            sb.template store_item<NS>(i, rb[i], nxt + NS * A_BYTES, B_BYTES);
+                            sb.template store_item<NS>(i, rb[i], nxt + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
                             sb.load_item(i, rb[i], k2, K);
                         }
                 }
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
         } else {
             __syncthreads();  // everyone done reading the single buffer
             if (more) {
-                sa.template store<NS>(ra, smem_raw, A_BYTES);
-                sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES);
+                sa.template store<NS>(ra, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
+                sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
             }
             __syncthreads();
         }
