@@ -88,7 +88,7 @@ def cpu_baseline(L, seed):
     from oracle import structure as ostr
     from e3diff_amd.bert import BertConfig
     from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
-    B = 4
+    B, timed = 8, 12          # ~10 s of CPU work on 16 cores
     common = dict(hidden_size=H, num_attention_heads=NH, intermediate_size=INTER, num_hidden_layers=LAYERS,
                   max_position_embeddings=L)
     m = ConditionalBertForDiffusionBase(BertConfig(**common),
@@ -104,7 +104,7 @@ def cpu_baseline(L, seed):
     torch.set_num_threads(cores)
     times = []
     with torch.no_grad():
-        for i in range(1 + 6):
+        for i in range(1 + timed):
             t0 = time.perf_counter()
             x = ostr.modulo_with_wrapped_range(ostr.p_sample(
                 fn, pk["ligand_attn_mask"], x, pk["receptor_seq"], pk["receptor_attn_mask"],
@@ -114,7 +114,7 @@ def cpu_baseline(L, seed):
     med = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": B / med, "unit": "pocket-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (CPU restatement of the reference incl. relative_key), structure model 12+12 layers, "
-                      f"B={B} x L={L} pockets, 1 warm-up + 6 timed reverse steps, median"}
+                      f"B={B} x L={L} pockets, 1 warm-up + {timed} timed reverse steps, median"}
 
 
 def main():
