@@ -88,7 +88,7 @@ def cpu_baseline(L, seed):
     from oracle import structure as ostr
     from e3diff_amd.bert import BertConfig
     from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
-    B, timed = 8, 12          # ~10 s of CPU work on 16 cores
+    B, warm, timed = 8, 3, 10   # 3 warm-up + >= 10 timed steps; ~10 s of CPU work on 16 cores
     common = dict(hidden_size=H, num_attention_heads=NH, intermediate_size=INTER, num_hidden_layers=LAYERS,
                   max_position_embeddings=L)
     m = ConditionalBertForDiffusionBase(BertConfig(**common),
@@ -104,17 +104,77 @@ def cpu_baseline(L, seed):
     torch.set_num_threads(cores)
     times = []
     with torch.no_grad():
-        for i in range(1 + timed):
+        for i in range(warm + timed):
             t0 = time.perf_counter()
             x = ostr.modulo_with_wrapped_range(ostr.p_sample(
                 fn, pk["ligand_attn_mask"], x, pk["receptor_seq"], pk["receptor_attn_mask"],
                 pk["receptor_angles"], torch.full((B,), 999 - i), betas))
             times.append(time.perf_counter() - t0)
             print(f"[cpu_baseline] step {i}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
-    med = sorted(times[1:])[len(times[1:]) // 2]
+    med = sorted(times[warm:])[len(times[warm:]) // 2]
     return {"value": B / med, "unit": "pocket-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (CPU restatement of the reference incl. relative_key), structure model 12+12 layers, "
-                      f"B={B} x L={L} pockets, 1 warm-up + {timed} timed reverse steps, median"}
+                      f"B={B} x L={L} pockets, {warm} warm-up + {timed} timed reverse steps, median"}
+
+
+def launch_workers(n):
+    """Self-contained multi-GPU launch: start ``n`` fresh copies of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in their environment, as torchrun would set them), one per GPU.  Runs BEFORE anything in this
+    process touches the GPU and never re-execs it.  Rank 0 prints the JSON line (inherited stdout); the
+    parent's exit code is the first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code and not rc:   # a dead rank would leave the others in the rendezvous / a collective forever
+                    rc = code
+                    for q in live:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+def plumbing_rehearsal(args, rank, world):
+    """E3D_BENCH_REHEARSAL=cpu: the control path of a multi-rank run with no GPU work at all."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    dt = 0.001 * (1 + rank)        # rank-dependent "elapsed": the reduction must return the slowest rank's
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "denoising-steps/sec (batched pocket graphs)", "rehearsal": "cpu plumbing only",
+                          "value": args.batch * world * args.steps / dt, "unit": "pocket-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "max_elapsed_s": dt, "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -134,9 +194,21 @@ def main():
                          "launch in a rocprofv3 trace of this command is then the launch `roofline` describes")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an external launcher: this process never touches the GPU, it only
+        # starts one fresh worker per GPU (no exec of an initialised process) and relays rank 0's JSON line
+        sys.exit(launch_workers(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU)")
+    rehearsal = os.environ.get("E3D_BENCH_REHEARSAL", "")
+    if rehearsal == "cpu":
+        # launcher / rendezvous / barrier / max-over-ranks / single-JSON-line plumbing without any GPU
+        # (tests/test_sharding_cpu.py); never a measurement
+        return plumbing_rehearsal(args, rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -144,14 +216,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # E3D_BENCH_REHEARSAL=1: the multi-rank control path on a ONE-GPU box (all ranks on cuda:0, gloo for the
         # barrier / max-over-ranks) -- a plumbing check, never a measurement
-        rehearsal = os.environ.get("E3D_BENCH_REHEARSAL") == "1"
-        if rehearsal:
+        if rehearsal == "1":
             local_rank = 0
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 

@@ -84,10 +84,21 @@ def validate(records):
     return sum(validate_record(r, i) for i, r in enumerate(records))
 
 
+def load_records(path):
+    """``torch.load(..., weights_only=True)``: the documented schema is only list / dict / str / tensors, which
+    the restricted unpickler accepts, so nothing in a user-supplied biolip.pt is ever executed."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:   # pickle.UnpicklingError and friends: anything beyond plain containers and tensors
+        raise BiolipSchemaError(
+            f"{path}: not loadable as plain containers + tensors (weights_only=True refused it: {e}). "
+            "A biolip.pt holds list[dict] of str / list[str] / tensors only (clean_data/data_preprocessing.py:880-892)."
+        ) from e
+
+
 def load(path):
-    """torch.load + validate (the file is a pickle of plain containers and tensors written by
-    torch.save: only load files you produced or trust)."""
-    records = torch.load(path, weights_only=False)
+    """safe load + validate."""
+    records = load_records(path)
     validate(records)
     return records
 

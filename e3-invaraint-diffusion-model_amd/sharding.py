@@ -94,7 +94,7 @@ class GradientAverager:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._flat, self._handles, self._pending, self._bound = {}, {}, None, False
+        self._flat, self._handles, self._pending, self._bound, self._touched = {}, {}, None, False, set()
         if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -125,11 +125,21 @@ class GradientAverager:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
         self._pending = [len(b) for b in self.buckets]
-        self._handles, self._bound = {}, True
+        self._handles, self._bound, self._touched = {}, True, set()
+
+    def _drop_unused(self):
+        """A parameter no rank's backward touched (the hook never fired anywhere: the autograd graph is the same
+        on every rank) gets ``grad = None`` back, as in a single-process run: the optimizer then skips it
+        (no weight decay on e.g. the sequence model's never-used ``receptor_feature_emb``), so single- and
+        multi-rank training produce the same checkpoint entries."""
+        for p in self.params:
+            if id(p) not in self._touched:
+                p.grad = None
 
     def _on_grad(self, p):
         if not self._bound:
             return
+        self._touched.add(id(p))
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
         if self._pending[i] == 0:
@@ -152,6 +162,7 @@ class GradientAverager:
                 self._handles[i].wait()
                 self._flat[i].div_(world)
             self._bound = False
+            self._drop_unused()
             return
         handles = []
         for i, bucket in enumerate(self.buckets):
@@ -170,9 +181,7 @@ class GradientAverager:
             off = 0
             for p in bucket:
                 g = flat[off:off + p.numel()].view_as(p) / world
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
+                if p.grad is not None:     # never-used parameters keep grad None (same graph on every rank)
                     p.grad.copy_(g)
                 off += p.numel()
 
@@ -181,5 +190,13 @@ def broadcast_parameters(module, src=0):
     """Make every rank start from rank ``src``'s weights (DDP construction semantics)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    # the collective writes behind autograd's back (no version bump, and ``.data`` has a counter of its own), so
+    # the received values are copied in with an ordinary in-place op: ``_version`` moves and the inference caches
+    # keyed on it (packed QKV, W^T, distance-table planes) are rebuilt on ranks that ran a forward before fit()
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            recv = t.detach().clone()
+            dist.broadcast(recv, src=src)
+            t.copy_(recv)
+    for m in module.modules():
+        m.__dict__.pop("_e3d_pack", None)

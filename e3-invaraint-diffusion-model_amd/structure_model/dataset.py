@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch.utils.data import Dataset
 
+from .. import biolip
 from .utils import CosineTables, modulo_with_wrapped_range
 
 RANDOM_SEED = 0
@@ -48,7 +49,7 @@ class LigandBindingSiteDataset(Dataset):
         self.max_len, self.pocket_ext = max_len, pocket_ext
         if records is None:
             print(f"Loading data from {filepath}")
-            records = torch.load(filepath, weights_only=False)
+            records = biolip.load_records(filepath)   # weights_only=True: nothing in the file is executed
         self.data = [dict(r) for r in records]
         for d in self.data:
             d["amino_acid"] = _one_hot("".join(d["amino_acid"]), AA_VOCAB)

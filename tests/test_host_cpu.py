@@ -222,3 +222,31 @@ def test_load_generated_angles_roundtrip(pkg, tmp_path):
     assert [c.shape for c in chunks] == [(2, 16, 8), (1, 16, 8)]
     assert np.allclose(chunks[0][0, :5].numpy(), arrs[0][-1]) and float(chunks[0][0, 5:].abs().sum()) == 0
     assert np.allclose(chunks[1][0, :3].numpy(), arrs[2])
+
+
+def test_biolip_file_is_loaded_without_executing_anything(tmp_path):
+    """A user-supplied biolip.pt goes through torch.load(weights_only=True): the schema's plain containers and
+    tensors load, a pickle that would run code is refused with a schema error (never executed)."""
+    import pickle
+
+    from e3diff_amd import biolip
+    from e3diff_amd.structure_model.dataset import LigandBindingSiteDataset
+    good = tmp_path / "biolip.pt"
+    biolip.write_synthetic(str(good), 6, seed=3)
+    assert len(biolip.load(str(good))) == 6
+    assert len(LigandBindingSiteDataset(str(good), None, max_len=64).data) == 6
+
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            return (open, (str(marker), "w"))
+
+    bad = tmp_path / "evil.pt"
+    with open(bad, "wb") as f:
+        pickle.dump([Evil()], f)
+    with pytest.raises(biolip.BiolipSchemaError):
+        biolip.load(str(bad))
+    with pytest.raises(biolip.BiolipSchemaError):
+        LigandBindingSiteDataset(str(bad), None)
+    assert not marker.exists()
