@@ -156,12 +156,13 @@ class _Attention(torch.autograd.Function):
         lib = hip.lib()
         ws = torch.empty((lib.e3d_relkey_attn_bwd_workspace_floats(B, nh, Lq, Lk, int(dist_emb is not None)),),
                          device=q.device, dtype=torch.float32)
-        hip.check(lib.e3d_relkey_attn_bwd_ex(
-            _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0), _p(v), Lk * v.stride(0),
-            v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse), _p(dout),
-            _p(dq), Lq * dq.stride(0), dq.stride(0), _p(dk), Lk * dk.stride(0), dk.stride(0),
-            _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, ctx.terms, ctx.drop[0], ctx.drop[1],
-            _stream()), "e3d_relkey_attn_bwd_ex")
+        with ops._timed("attn_bwd", (B, nh, Lq, Lk)):
+            hip.check(lib.e3d_relkey_attn_bwd_ex(
+                _p(q), Lq * q.stride(0), q.stride(0), _p(k), Lk * k.stride(0), k.stride(0), _p(v), Lk * v.stride(0),
+                v.stride(0), _p(dist_emb), max_pos, _p(key_mask), _p(out), _p(lse), _p(dout),
+                _p(dq), Lq * dq.stride(0), dq.stride(0), _p(dk), Lk * dk.stride(0), dk.stride(0),
+                _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, ctx.terms, ctx.drop[0], ctx.drop[1],
+                _stream()), "e3d_relkey_attn_bwd_ex")
         return dq_src, dkv_src, dE, None, None, None, None, None, None, None
 
 

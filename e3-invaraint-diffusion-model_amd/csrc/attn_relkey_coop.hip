@@ -371,12 +371,8 @@ int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t
              int64_t v_bs, int64_t v_rs, const bf16x8* e_frag, int P, const float* key_mask,
              float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip, hipStream_t s) {
     const size_t lds = 2 * KV_BUF_B + (size_t)W * RING_F * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_coop_kernel<W, RELKEY>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    e3d_allow_lds(lds_ok, attn_coop_kernel<W, RELKEY>, lds);
     const int groups = q_tiles / W;
     hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
                        k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, nh, Lq, Lk, groups, skip);
@@ -421,23 +417,17 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
     if (!dist_emb)
         return launch_any<false>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh, Lq,
                                  Lk, q_tiles, skip, s);
-    // distance table -> fragment-order bf16 planes, into the caller's scratch (e3d_attn_scratch_bytes) or, without
-    // one, a stream-ordered allocation
+    // distance table -> fragment-order bf16 planes in the caller's scratch (e3d_attn_scratch_bytes(Lk) bytes)
+    if (!e_scratch) {
+        e3d_set_error("attn_coop: rel-key attention needs the caller's scratch for the distance-table planes");
+        return -1;
+    }
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
     bf16x8* planes = reinterpret_cast<bf16x8*>(e_scratch);
-    if (!planes) {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&planes), (size_t)n_items * sizeof(bf16x8), s);
-        if (e != hipSuccess) {
-            e3d_set_error("attn_coop: hipMallocAsync of the distance-table planes failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-    }
-    if (!(e_ready && e_scratch))   // e_ready: the caller kept the planes of this (dist_emb, Lk) from an earlier call
+    if (!e_ready)   // e_ready: the caller kept the planes of this (dist_emb, Lk) from an earlier call
         hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
-    const int rc = launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, q_tiles, skip, s);
-    if (!e_scratch) (void)hipFreeAsync(planes, s);
-    return rc;
+    return launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh, Lq, Lk,
+                            q_tiles, skip, s);
 }
 
 #ifdef E3D_ATTN_STAMPS

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <math.h>
+#include <atomic>
 
 #include "../../include/e3d_hip.h"
 
@@ -25,6 +26,45 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
             return -1;               \
         }                            \
     } while (0)
+
+// One-time launch setup PER DEVICE (dynamic-LDS opt-in of a kernel, CU count): function attributes and device
+// properties belong to the device that is current when they are set / read, so a process that drives several GPUs
+// (or several host threads) must not share one process-wide flag.  ``mask`` holds one bit per device ordinal;
+// ``f(device)`` is idempotent, so two threads racing through the first launch is harmless.
+static inline int e3d_current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+template <typename F>
+static inline void e3d_once_per_device(std::atomic<uint64_t>& mask, F&& f) {
+    const int d = e3d_current_device();
+    const uint64_t bit = 1ull << (d & 63);
+    if (!(mask.load(std::memory_order_acquire) & bit)) {
+        f(d);
+        mask.fetch_or(bit, std::memory_order_release);
+    }
+}
+// CUs of the current device, rounded down to whole XCD rounds (tile t then runs on XCD t % 8, as xcd_remap assumes)
+static inline int e3d_cu_count() {
+    static std::atomic<int> n_cu[64];
+    const int d = e3d_current_device() & 63;
+    int n = n_cu[d].load(std::memory_order_relaxed);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        n -= n % 8;
+        if (n <= 0) n = 8;
+        n_cu[d].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+template <typename K>
+static inline void e3d_allow_lds(std::atomic<uint64_t>& mask, K kernel, size_t lds_bytes) {
+    e3d_once_per_device(mask, [&](int) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes);
+    });
+}
 
 static inline int e3d_launch_status(const char* what) {
     hipError_t e = hipGetLastError();

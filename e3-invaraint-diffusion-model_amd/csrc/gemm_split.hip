@@ -643,15 +643,9 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
                int K, hipStream_t s) {
     const int tiles_m = M / BT, tiles_n = N / BT;
     constexpr size_t lds = 2 * 2 * 2 * BT * ROW64;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        n_cu -= n_cu % 8;   // whole XCD rounds: tile t then runs on XCD t % 8, as the remap assumes
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256p_kernel<ACT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    e3d_allow_lds(lds_ok, gemm_split256p_kernel<ACT>, lds);
+    const int n_cu = e3d_cu_count();
     const int total = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_split256p_kernel<ACT>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias,
                        out, ldc, N, K, tiles_m, tiles_n);
@@ -667,12 +661,8 @@ int launch256(const float* A, int64_t lda, const float* W, const float* bias, fl
     constexpr int TM = WR * 128, TN = WC * 64;
     const int tiles_m = (M + TM - 1) / TM, tiles_n = N / TN;
     const size_t lds = (size_t)NBUF * NS * (TM + TN) * ROW64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    e3d_allow_lds(lds_ok, gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>, lds);
     hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>), dim3(tiles_m * tiles_n), dim3(WR * WC * 64), lds, s,
                        A, lda, W, bias, out, ldc, M, N, K, tiles_m, tiles_n);
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
@@ -728,12 +718,8 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>, lds);
     // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count
     int splits = 1;
     if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 32 * WM && K >= 1024) {

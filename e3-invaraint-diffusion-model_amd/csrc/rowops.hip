@@ -200,12 +200,8 @@ extern "C" int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, co
     const dim3 grid(blocks), block(256);
     const size_t lds = (size_t)F * H * sizeof(float);
     DISPATCH_V(H, {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_layernorm_kernel<V>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32 * H * (int)sizeof(float));
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> lds_ok{0};
+        e3d_allow_lds(lds_ok, embed_layernorm_kernel<V>, 32 * (size_t)H * sizeof(float));
         hipLaunchKernelGGL(embed_layernorm_kernel<V>, grid, block, lds, (hipStream_t)stream, x, F, W, b, gamma, beta,
                            eps, post_add, rows_per_add, z_out, out, M);
     });

@@ -18,13 +18,52 @@ def _stream():
 TRACE = None
 
 
+# roctx ranges around the hot-path kernels (K1 rel-key attention, K2 cross attention, K3 their
+# backward, K4 adaLN gate, K5 LayerNorm / GEMM epilogues, K6 DDPM update + wrap, K7 discrete posterior; plus the
+# GEMMs).  E3D_ROCTX=1 (tools/profile_round.sh sets it) loads libroctx64 and brackets every launch of those ops;
+# `rocprofv3 --marker-trace` then shows the ranges next to the kernel trace.  Off by default: two ctypes calls
+# per launch are measurable in the single-pocket loop.
+_ROCTX = None
+
+
+def _roctx():
+    global _ROCTX
+    if _ROCTX is None:
+        _ROCTX = False
+        if os.environ.get("E3D_ROCTX") == "1":
+            import ctypes
+            for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+                try:
+                    lib = ctypes.CDLL(name)
+                    lib.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                    _ROCTX = lib
+                    break
+                except OSError:
+                    continue
+    return _ROCTX
+
+
+ROCTX_NAMES = {"attn_relkey": b"K1 relkey_attention_fwd", "attn_cross": b"K2 cross_attention_fwd",
+               "attn_bwd": b"K3 attention_bwd", "adaln_gate": b"K4 adaln_gate",
+               "residual_layernorm": b"K5 residual_layernorm", "embed_layernorm": b"K5 embed_layernorm",
+               "gemm": b"K5 gemm_bias_act", "ddpm_step_wrap": b"K6 ddpm_step_wrap",
+               "discrete_posterior": b"K7 discrete_posterior_sample", "discrete_q_sample": b"K7 discrete_q_sample"}
+
+
 class _timed:
-    def __init__(self, name, meta):
+    """Brackets one launch: HIP events on the launch stream when bench.py collects a TRACE, a roctx range when
+    E3D_ROCTX=1."""
+
+    def __init__(self, name, meta=None):
         self.on = TRACE is not None
+        self.rx = _roctx()
+        self.name = name
         if self.on:
             self.rec = (name, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), meta)
 
     def __enter__(self):
+        if self.rx:
+            self.rx.roctxRangePushA(ROCTX_NAMES.get(self.name, self.name.encode()))
         if self.on:
             self.rec[1].record()
 
@@ -32,6 +71,8 @@ class _timed:
         if self.on:
             self.rec[2].record()
             TRACE.append(self.rec)
+        if self.rx:
+            self.rx.roctxRangePop()
 
 
 def _chk(t, name, dtype=torch.float32):
@@ -84,6 +125,24 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
                 _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _stream()),
                 "e3d_gemm_bias_act_f32_split")
     return out
+
+
+class arithmetic:
+    """``with ops.arithmetic("bf16x6"):`` -- GEMM and attention arithmetic for the enclosed calls (entry points use it
+    to mirror the precision the reference runs that script at; E3D_GEMM_MODE / E3D_ATTN_MODE in the environment
+    win over an entry point's default)."""
+
+    def __init__(self, mode, respect_env=True):
+        self.gemm = os.environ.get("E3D_GEMM_MODE", mode) if respect_env else mode
+        self.attn = os.environ.get("E3D_ATTN_MODE", self.gemm) if respect_env else mode
+
+    def __enter__(self):
+        self.prev = (set_gemm_mode(self.gemm), set_attn_mode(self.attn))
+        return self
+
+    def __exit__(self, *exc):
+        set_gemm_mode(self.prev[0])
+        set_attn_mode(self.prev[1])
 
 
 ATTN_MODE = os.environ.get("E3D_ATTN_MODE", GEMM_MODE)   # same choices and meaning as GEMM_MODE
@@ -175,8 +234,9 @@ def residual_layernorm(x, residual, gamma, beta, eps, want_s=False):
     M, H = x.shape
     out = torch.empty_like(x)
     s = torch.empty_like(x) if want_s else None
-    hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s),
-                                                   _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
+    with _timed("residual_layernorm", (M, H)):
+        hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s),
+                                                       _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
     return (out, s) if want_s else out
 
 
@@ -187,8 +247,9 @@ def adaln_gate(x, y, mod, branch, rows_per_cond):
     M, H = x.shape
     assert mod.shape[1] == 6 * H and mod.shape[0] * rows_per_cond == M, (mod.shape, M, rows_per_cond)
     out = torch.empty_like(x)
-    hip.check(hip.lib().e3d_adaln_gate_fwd(_p(x), _p(y), _p(mod), branch, rows_per_cond, _p(out),
-                                           M, H, _stream()), "e3d_adaln_gate_fwd")
+    with _timed("adaln_gate", (M, H)):
+        hip.check(hip.lib().e3d_adaln_gate_fwd(_p(x), _p(y), _p(mod), branch, rows_per_cond, _p(out),
+                                               M, H, _stream()), "e3d_adaln_gate_fwd")
     return out
 
 
@@ -204,9 +265,10 @@ def embed_layernorm(x, weight, bias, gamma, beta, eps, post_add=None, rows_per_a
         assert post_add.is_contiguous() and post_add.shape == (M // rows_per_add, H)
     out = torch.empty((M, H), device=x.device, dtype=torch.float32)
     z = torch.empty_like(out) if want_z else None
-    hip.check(hip.lib().e3d_embed_layernorm_fwd(_p(x), F, _p(weight), _p(bias), _p(gamma), _p(beta), eps,
-                                                _p(post_add), rows_per_add, _p(z), _p(out), M, H, _stream()),
-              "e3d_embed_layernorm_fwd")
+    with _timed("embed_layernorm", (M, H)):
+        hip.check(hip.lib().e3d_embed_layernorm_fwd(_p(x), F, _p(weight), _p(bias), _p(gamma), _p(beta), eps,
+                                                    _p(post_add), rows_per_add, _p(z), _p(out), M, H, _stream()),
+                  "e3d_embed_layernorm_fwd")
     return (out, z) if want_z else out
 
 
@@ -228,9 +290,10 @@ def ddpm_step_wrap(x, eps_hat, noise, sqrt_recip_alpha, beta, sqrt_one_minus_ab,
     assert x.is_contiguous() and eps_hat.is_contiguous() and (noise is None or noise.is_contiguous())
     if out is None:
         out = torch.empty_like(x)
-    hip.check(hip.lib().e3d_ddpm_step_wrap(_p(x), _p(eps_hat), _p(noise), sqrt_recip_alpha, beta,
-                                           sqrt_one_minus_ab, sigma, int(wrap), _p(out), x.numel(), _stream()),
-              "e3d_ddpm_step_wrap")
+    with _timed("ddpm_step_wrap"):
+        hip.check(hip.lib().e3d_ddpm_step_wrap(_p(x), _p(eps_hat), _p(noise), sqrt_recip_alpha, beta,
+                                               sqrt_one_minus_ab, sigma, int(wrap), _p(out), x.numel(), _stream()),
+                  "e3d_ddpm_step_wrap")
     return out
 
 
@@ -244,8 +307,9 @@ def ddpm_step_wrap_table(x, eps_hat, noise, coef_table, t_dev, wrap=True, out=No
     assert coef_table.dim() == 2 and coef_table.shape[1] == 4
     if out is None:
         out = torch.empty_like(x)
-    hip.check(hip.lib().e3d_ddpm_step_wrap_table(_p(x), _p(eps_hat), _p(noise), _p(coef_table), _p(t_dev), int(wrap),
-                                                 _p(out), x.numel(), _stream()), "e3d_ddpm_step_wrap_table")
+    with _timed("ddpm_step_wrap"):
+        hip.check(hip.lib().e3d_ddpm_step_wrap_table(_p(x), _p(eps_hat), _p(noise), _p(coef_table), _p(t_dev), int(wrap),
+                                                     _p(out), x.numel(), _stream()), "e3d_ddpm_step_wrap_table")
     return out
 
 
@@ -269,9 +333,10 @@ def discrete_posterior_sample(xt_idx, logits, qsb, qtb, u=None, want_prob=False)
     assert qsb.shape == (B, C, C) and qtb.shape == (B, C, C) and xt_idx.shape == (B, L)
     out = torch.empty((B, L), device=logits.device, dtype=torch.int32)
     prob = torch.empty((B, L, C), device=logits.device, dtype=torch.float32) if want_prob else None
-    hip.check(hip.lib().e3d_discrete_posterior_sample(
-        _p(xt_idx), _p(logits), _p(qsb), _p(qtb), _p(u), 0 if u is None else 1, _p(out), _p(prob),
-        B, L, C, _stream()), "e3d_discrete_posterior_sample")
+    with _timed("discrete_posterior"):
+        hip.check(hip.lib().e3d_discrete_posterior_sample(
+            _p(xt_idx), _p(logits), _p(qsb), _p(qtb), _p(u), 0 if u is None else 1, _p(out), _p(prob),
+            B, L, C, _stream()), "e3d_discrete_posterior_sample")
     return (out, prob) if want_prob else out
 
 
@@ -282,6 +347,7 @@ def discrete_q_sample(x0_idx, qtb, u=None):
     C = qtb.shape[-1]
     assert x0_idx.is_contiguous() and qtb.is_contiguous() and qtb.shape == (B, C, C)
     out = torch.empty((B, L), device=qtb.device, dtype=torch.int32)
-    hip.check(hip.lib().e3d_discrete_q_sample(_p(x0_idx), _p(qtb), _p(u), 0 if u is None else 1, _p(out),
-                                              B, L, C, _stream()), "e3d_discrete_q_sample")
+    with _timed("discrete_q_sample"):
+        hip.check(hip.lib().e3d_discrete_q_sample(_p(x0_idx), _p(qtb), _p(u), 0 if u is None else 1, _p(out),
+                                                  B, L, C, _stream()), "e3d_discrete_q_sample")
     return out

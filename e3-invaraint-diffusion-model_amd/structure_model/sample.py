@@ -33,6 +33,11 @@ OUTPUT = "./data/output.pkl"
 DATA_FILE = "./data/biolip.pt"
 GPU_ID = 0
 STEP = 1  # stride over timesteps; >1 trades quality for speed (reference sample.py:16)
+# Arithmetic of this entry point.  The reference's structure_model/sample.py never calls
+# torch.set_float32_matmul_precision (only the train scripts and the sequence sampler set "medium"), i.e. it
+# samples at full fp32: ``sample()`` therefore runs the fp32-grade bf16x6 kernels unless E3D_GEMM_MODE says
+# otherwise.  (bench.py times bf16x3 -- inside the 1e-4 contract -- and reports every mode on its line.)
+ARITHMETIC = "bf16x6"
 
 CONFIG = {
     "pocket_ext": 0,
@@ -274,11 +279,12 @@ def sample(model, test_angle_ds, all_batches: bool = False):
         print(f"Generating Batch {idx}/{len(ligand_mask)}")
         lengths = lm.sum(dim=1).int()
         x_T = test_angle_ds.sample_noise(torch.zeros((len(lengths), pad, feature_size)))
-        sampled = p_sample_loop(
-            model=model, ligand_mask=lm.to(DEVICE), ligand_angle_noise=x_T.to(DEVICE),
-            receptor_seq=receptor_seq[idx].to(DEVICE), receptor_mask=receptor_mask[idx].to(DEVICE),
-            receptor_angle=receptor_angle[idx].to(DEVICE), total_timesteps=test_angle_ds.timesteps,
-            betas=test_angle_ds.alpha_beta_terms["betas"], trim_padding=True)   # sliced to l_i right below
+        with ops.arithmetic(ARITHMETIC):
+            sampled = p_sample_loop(
+                model=model, ligand_mask=lm.to(DEVICE), ligand_angle_noise=x_T.to(DEVICE),
+                receptor_seq=receptor_seq[idx].to(DEVICE), receptor_mask=receptor_mask[idx].to(DEVICE),
+                receptor_angle=receptor_angle[idx].to(DEVICE), total_timesteps=test_angle_ds.timesteps,
+                betas=test_angle_ds.alpha_beta_terms["betas"], trim_padding=True)   # sliced to l_i right below
         retval.extend(sampled[:, i, :l, :].numpy() for i, l in enumerate(lengths))
         if not all_batches:
             break

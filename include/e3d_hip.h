@@ -67,7 +67,14 @@ int e3d_relkey_attn_fwd(const float* q, int64_t q_bs, int64_t q_rs,
 
 /* Same contract as e3d_relkey_attn_fwd on the bf16 matrix cores: K, E, Q, V and the softmax
  * probabilities enter the MFMAs as 2 (terms = 3) or 3 (terms = 6, fp32-grade) bf16 split terms,
- * accumulation, softmax and the rel-key skew stay fp32. */
+ * accumulation, softmax and the rel-key skew stay fp32.
+ * Softmax exponential: exp(x) is evaluated as exp2(x * log2(e)) on the hardware v_exp_f32 (<= 1 ulp of fp32
+ * exp2; the product x * log2(e) rounds once more), not libm expf -- inside the 1e-4 contract
+ * (tests/test_kernels_gpu.py), stated here because SURVEY H2 asks for it.  The exact-fp32 entry point above
+ * (e3d_relkey_attn_fwd) uses libm expf.
+ * This entry point takes no scratch and never allocates: rel-key calls run the per-wave kernel.  The faster
+ * workgroup-cooperative kernel needs the distance table as bf16 planes in caller-provided memory -- bind
+ * e3d_relkey_attn_fwd_split_ex (below) for that. */
 int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
                               const float* k, int64_t k_bs, int64_t k_rs,
                               const float* v, int64_t v_bs, int64_t v_rs,
@@ -203,10 +210,9 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
 
 /* The full form of the two above: ``e_scratch`` (device, >= e3d_attn_scratch_bytes(Lk) bytes, 16-byte
  * aligned, or NULL) receives the fragment-order bf16 hi/lo planes of dist_emb that the cooperative kernel
- * reads; with NULL the library takes a stream-ordered allocation (hipMallocAsync), which callers that
- * capture the stream into a hipGraph should avoid.  ``e_scratch_ready`` != 0: the scratch still holds the planes
- * written by an earlier call with the same dist_emb values and Lk (constant weights: inference) -- the 5-us
- * pre-pass is skipped. */
+ * reads; with NULL (and a dist_emb) the per-wave kernel serves the call instead -- the library never
+ * allocates.  ``e_scratch_ready`` != 0: the scratch still holds the planes written by an earlier call with the
+ * same dist_emb values and Lk (constant weights: inference) -- the 5-us pre-pass is skipped. */
 int64_t e3d_attn_scratch_bytes(int Lk);
 int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                  int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,

@@ -96,3 +96,29 @@ def reverse_step_tolerance(betas, t_index, eps_scale=1.0, rel=1e-4):
     abar = torch.cumprod(alphas, 0)
     amp = (1.0 / torch.sqrt(alphas[t_index])) * betas[t_index] / torch.sqrt(1.0 - abar[t_index])
     return rel * eps_scale * float(amp) + 2e-5
+
+
+def elementwise_err(a, b, floor=1e-3):
+    """Element-wise relative-or-absolute error |a-b| / max(|b|, floor * rms(b)) -- the stricter companion of
+    ``rel_err`` (which divides every element by the LARGEST reference value).  Returns (99.9th percentile, max)."""
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    rms = b.pow(2).mean().sqrt().clamp_min(1e-30)
+    e = (a - b).abs() / torch.maximum(b.abs(), floor * rms)
+    k = max(1, int(round(0.999 * e.numel())))
+    return e.kthvalue(k).values.item(), e.max().item()
+
+
+def rescaled_state_dict(sd, weight_scale=4.0, gamma_range=(0.5, 2.0), seed=0):
+    """A second weight regime for the arithmetic-margin tests: every Linear weight x ``weight_scale`` (attention
+    logits x scale^2: peaky softmax rows), LayerNorm gammas spread log-uniformly over ``gamma_range``."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    lo, hi = math.log(gamma_range[0]), math.log(gamma_range[1])
+    for k, v in sd.items():
+        if "LayerNorm.weight" in k or "layer_norm.weight" in k:
+            out[k] = torch.exp(lo + (hi - lo) * torch.rand(v.shape, generator=g))
+        elif v.dim() == 2 and k.endswith(".weight") and "distance_embedding" not in k:
+            out[k] = v * weight_scale
+        else:
+            out[k] = v.clone()
+    return out

@@ -208,7 +208,7 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol):
     return max(worst.values())
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-4), ("bf16x3", 2e-3)])
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4)])   # measured on MI355X: 4.0e-6 / 4.1e-5
 def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, capsys):
     """Whole structure model, loss of the reference (wrapped L1 x4 + smooth-L1 x4), every parameter
     gradient against CPU autograd of the oracle."""

@@ -250,3 +250,34 @@ def test_biolip_file_is_loaded_without_executing_anything(tmp_path):
     with pytest.raises(biolip.BiolipSchemaError):
         LigandBindingSiteDataset(str(bad), None)
     assert not marker.exists()
+
+
+def test_joint_handover_matches_reference_load_generated_angles(pkg, tmp_path):
+    """Pins SURVEY 8(f) rank 1 against the reference itself: tests/golden/joint_handover.pt holds the chunks the
+    reference's ``load_generated_angles`` (sequence_model/sample_by_generated_angles.py:54-66, ast-extracted and run
+    by tests/golden/make_joint_fixture.py) produced from a pickle of ragged per-ligand [l_i, 8] arrays.
+    (1) the product's file loader returns the same chunks bit for bit; (2) the on-device hand-over
+    ``angles_from_trajectory`` -- the path the joint sampler really takes, no pickle -- produces exactly that padded
+    tensor from a structure trajectory whose padding rows hold arbitrary values."""
+    import pickle
+    from e3diff_amd.sequence_model.sample_by_generated_angles import angles_from_trajectory, load_generated_angles
+    fx = torch.load(os.path.join(GOLDEN, "joint_handover.pt"), weights_only=True)
+    cfg, lengths = fx["config"], fx["lengths"]
+    p = tmp_path / "output.pkl"
+    with open(p, "wb") as f:
+        pickle.dump([a.numpy() for a in fx["arrays"]], f)
+    got = load_generated_angles(str(p), max_seq_len=cfg["max_seq_len"], batch_size=cfg["batch_size"])
+    assert len(got) == len(fx["chunks"])
+    for a, b in zip(got, fx["chunks"]):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    # the device path: a [T,B,L,8] trajectory whose last step carries the generated angles on the valid rows and
+    # garbage on the padding rows (the sampler noises padding too, SURVEY H4)
+    want = torch.cat(fx["chunks"])
+    n, L = want.shape[0], cfg["max_seq_len"]
+    mask = (torch.arange(L)[None, :] < torch.tensor(lengths)[:, None]).float()
+    g = torch.Generator().manual_seed(2)
+    traj = torch.randn(3, n, L, 8, generator=g)
+    for i, a in enumerate(fx["arrays"]):
+        traj[-1, i, :lengths[i]] = a
+    assert torch.equal(angles_from_trajectory(traj, mask), want)
+    assert torch.equal(angles_from_trajectory(traj[-1], mask), want)
