@@ -71,16 +71,18 @@ def small_k_wgrad(g, x, transpose_out=False, want_bias=True):
 
 # ----------------------------------------------------------------------------- autograd Functions
 def _transposed_weight(weight):
-    """W^T [K,N] contiguous, cached on the tensor per version: the input-gradient GEMM dz . W then runs in the
-    forward (both operands K-contiguous) layout, which is ~25 % faster than reading W "K-major" (one dword per
-    lane); one 5-us transpose per weight and optimizer step."""
+    """W^T [K,N] contiguous, cached on the tensor until it changes (ops.weight_key): the input-gradient GEMM dz . W
+    then runs in the forward (both operands K-contiguous) layout, which is ~25 % faster than reading W "K-major" (one
+    dword per lane); one 5-us transpose per weight and optimizer step (gradient accumulation over several backward
+    passes re-uses it)."""
     w = weight.detach()
+    key = ops.weight_key(w)     # (generation, data_ptr, version): a fused optimizer step changes only the generation
     ent = getattr(weight, "_e3d_wt", None)
-    if ent is not None and ent[0] == weight._version and ent[1] == w.data_ptr():
-        return ent[2]
+    if ent is not None and ent[0] == key:
+        return ent[1]
     wt = w.t().contiguous()
     try:
-        weight._e3d_wt = (weight._version, w.data_ptr(), wt)
+        weight._e3d_wt = (key, wt)
     except AttributeError:
         pass
     return wt

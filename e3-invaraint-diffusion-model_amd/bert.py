@@ -123,7 +123,7 @@ def _packed(owner, name, tensors):
     onto query/key/value by autograd."""
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         return torch.cat(list(tensors), dim=0)
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    key = ops.weight_key(*tensors)    # includes the optimizer-step generation: fused optimizers do not bump _version
     cache = owner.__dict__.setdefault("_e3d_pack", {})
     hit = cache.get(name)
     if hit is None or hit[0] != key:

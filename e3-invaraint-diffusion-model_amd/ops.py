@@ -88,6 +88,32 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ---------------------------------------------------------------------------------------------- derived-weight caches
+# Tensors derived from parameters (packed QKV weights, W^T for the input-gradient GEMM, the distance-table planes) are
+# cached on their source and keyed on (tensor._version, data_ptr, PARAM_GENERATION).  ``_version`` alone is NOT enough:
+# torch's fused optimizer kernels (torch.optim.AdamW(fused=True), used by training.adamw) update parameters without
+# bumping it, so a cache keyed only on the version would keep serving the weights of the first step.  Every
+# optimizer step therefore bumps PARAM_GENERATION through a global post-step hook (registered at import); code that
+# writes parameter storage by other means behind autograd's back calls ``invalidate_weight_caches()`` itself.
+PARAM_GENERATION = 0
+
+
+def invalidate_weight_caches(*_args, **_kwargs):
+    global PARAM_GENERATION
+    PARAM_GENERATION += 1
+
+
+def weight_key(*tensors):
+    return (PARAM_GENERATION,) + tuple((t.data_ptr(), t._version) for t in tensors)
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(invalidate_weight_caches)
+except ImportError:      # very old torch: training.fit() bumps the generation after every step instead
+    pass
+
+
 # GEMM arithmetic: "f32" = exact fp32 MFMA; "bf16x3" / "bf16x6" = fp32 operands split into 2 / 3
 # bf16 terms on the bf16 matrix cores with fp32 accumulation (gemm_split.hip).  bf16x6 is fp32-grade
 # (4e-7 end-to-end vs 1.8e-6 for fp32 itself), bf16x3 ~2.6e-5 end-to-end (tolerance 1e-4).
@@ -212,13 +238,13 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
                 # inference (grad disabled): the planes are kept across calls, keyed by the tensor's version / storage
                 infer = not torch.is_grad_enabled()
                 ent = getattr(dist_emb, "_e3d_planes", None) if infer else None
-                if ent is not None and ent[0] == (dist_emb._version, dist_emb.data_ptr(), Lk):
+                if ent is not None and ent[0] == weight_key(dist_emb) + (Lk,):
                     scratch, ready = ent[1], 1
                 else:
                     scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
                     if infer and not torch.cuda.is_current_stream_capturing():
                         try:
-                            dist_emb._e3d_planes = ((dist_emb._version, dist_emb.data_ptr(), Lk), scratch)
+                            dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk,), scratch)
                         except AttributeError:
                             pass
             p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)

@@ -25,7 +25,7 @@ def adamw(params, lr, weight_decay):
         return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
 
 
-from . import sharding
+from . import ops, sharding
 
 
 def move_batch(batch, device):
@@ -80,6 +80,7 @@ def fit(model, train_loader, val_loader=None, *, max_epochs, min_epochs=0, gradi
             if gradient_clip:
                 torch.nn.utils.clip_grad_norm_(params, gradient_clip)   # global norm of the averaged grads
             optim.step()
+            ops.invalidate_weight_caches()           # belt and braces beside the global optimizer hook (ops.py)
             if sched is not None and sched.get("interval") == "step":
                 sched["scheduler"].step()
             losses.append(float(loss.detach()))

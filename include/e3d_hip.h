@@ -82,6 +82,12 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
                               float* out, float* lse, int B, int nh, int Lq, int Lk, int terms,
                               void* stream);
 
+/* Diagnostic switch (A/B timing, tools/bench_kernels.py): which kernel form serves large-M forward launches of
+ * e3d_gemm_bias_act_f32_split with terms = 3 -- 4 = persistent 256x256 (default), 3 = 256x256 with interleaved
+ * staging, 1 = classic 256x256 loop, 0 = 256x128.  Results are identical in every form (same products, same
+ * accumulation order).  pref < 0 only queries.  Returns the previous value. */
+int e3d_gemm_kernel_select(int pref);
+
 /* Process-wide switch of the split attention kernels (default 1): stop the key sweep after the tile
  * holding the last valid key of the item.  Trailing all-padding tiles contribute exp(-10000 - m) = 0.0f
  * exactly, so results are bit-identical; 0 restores the dense sweep (timing comparisons).  Returns the

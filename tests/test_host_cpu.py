@@ -281,3 +281,34 @@ def test_joint_handover_matches_reference_load_generated_angles(pkg, tmp_path):
         traj[-1, i, :lengths[i]] = a
     assert torch.equal(angles_from_trajectory(traj, mask), want)
     assert torch.equal(angles_from_trajectory(traj[-1], mask), want)
+
+
+def test_weight_caches_follow_fused_optimizer_steps(pkg):
+    """torch's fused AdamW updates parameters WITHOUT bumping ``_version`` (checked here, so that the day torch changes
+    that the comment in ops.py can go); the derived-weight caches (packed QKV, W^T, distance-table planes) must
+    nevertheless be rebuilt after an optimizer step: their key carries ops.PARAM_GENERATION, bumped by a global
+    optimizer post-step hook."""
+    from e3diff_amd import autograd as AG, bert, ops
+    w = torch.nn.Parameter(torch.randn(8, 4))
+    opt = torch.optim.AdamW([w], lr=1e-2, fused=True)
+    wt0 = AG._transposed_weight(w)
+    assert AG._transposed_weight(w) is wt0                       # cached while nothing changes
+    att = bert.BertSelfAttention(bert.BertConfig(hidden_size=256, num_attention_heads=4, max_position_embeddings=8))
+    opt2 = torch.optim.AdamW(att.parameters(), lr=1e-2, fused=True)
+    with torch.no_grad():
+        pack0 = bert.qkv_weights(att)[0]
+        assert bert.qkv_weights(att)[0] is pack0
+    w.grad = torch.ones_like(w)
+    v0, gen0 = w._version, ops.PARAM_GENERATION
+    opt.step()
+    assert ops.PARAM_GENERATION > gen0
+    fused_bumps_version = w._version != v0
+    wt1 = AG._transposed_weight(w)
+    assert wt1 is not wt0 and torch.equal(wt1, w.detach().t()) and not torch.equal(wt1, wt0)
+    for p in att.parameters():
+        p.grad = torch.ones_like(p)
+    opt2.step()
+    with torch.no_grad():
+        pack1 = bert.qkv_weights(att)[0]
+    assert pack1 is not pack0 and torch.equal(pack1[:256], att.query.weight.detach())
+    print("fused AdamW bumps _version:", fused_bumps_version)
