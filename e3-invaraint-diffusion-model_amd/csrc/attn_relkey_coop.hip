@@ -6,8 +6,15 @@
 //   * every key tile's K and V are fetched from HBM/L2 once per workgroup (not once per wave), split
 //     into bf16 hi/lo planes once, and parked in a double-buffered LDS image that all waves read
 //     their MFMA fragments from; the loads of tile t+1 are in flight while tile t is computed;
-//   * V is stored TRANSPOSED ([d][key], keys in the PV-operand order) so that the A operand of
-//     O^T += V^T P^T is one ds_read_b128 per fragment instead of 8 scalar gathers;
+//   * V is parked row-major ([key][d], 192-byte rows) and the A operand of O^T += V^T P^T is fetched with
+//     ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group reads a 4-key x 16-dim block and
+//     every lane receives its head dim of the 4 keys -- exactly the keys rho(8 st + j, half) the P^T registers
+//     hold, so staging V costs two 8-byte LDS stores per thread and tile (a transposed image cost eight
+//     2-byte scatters plus their address arithmetic);
+//   * softmax in the exp2 domain: Q is pre-multiplied by log2(e) / sqrt(d) before it is split, so scores leave
+//     the MFMAs ready for v_exp_f32; the running maximum is only raised when a tile exceeds it by more than
+//     2^RESCALE_TAU (deferred rescale: O and l stay relative to a slightly stale maximum, which cancels in O / l),
+//     so the 32 + 2 multiplies of the rescale are skipped on almost every tile;
 //   * the distance embedding E is split into bf16 planes by a tiny pre-pass (it is a parameter:
 //     (2P-1) x 64 values) and each wave reads its 32-row block as MFMA fragments straight from
 //     those planes (L2-resident, 130 KB), so E costs neither LDS nor VALU in the hot loop;
@@ -29,8 +36,12 @@ constexpr int RING_LD = 34;
 constexpr int RING_F = 64 * RING_LD;          // 2176 floats: also holds the 32 x 68 output tile
 constexpr int OUT_LD = 68;
 constexpr int K_ROW_B = 144;                  // 64 bf16 + 16 B pad: conflict-free b128 fragment reads
-constexpr int V_ROW_B = 80;                   // 32 bf16 + 16 B pad
-constexpr int K_PLANE_B = 32 * K_ROW_B, V_PLANE_B = 64 * V_ROW_B;
+constexpr int V_ROW_B = 192;                  // 64 bf16 + 64 B pad: 4 consecutive key rows x 64 B hit 64 distinct banks
+constexpr int K_PLANE_B = 32 * K_ROW_B, V_PLANE_B = 32 * V_ROW_B;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+constexpr float Q_SCALE = 0.125f * LOG2E;     // 1 / sqrt(64), scores in log2 units
+constexpr float MASK_BIAS = -10000.0f * LOG2E;
+float g_rescale_tau = 8.0f;                   // raise the running maximum only past m + 8 (probabilities <= 2^8); e3d_attn_rescale_tau
 constexpr int KV_BUF_B = 2 * K_PLANE_B + 2 * V_PLANE_B + 128;   // + 32 floats of key bias
 
 __device__ __forceinline__ void split4x2(const f32x4 v, bf16x4& hi, bf16x4& lo) {
@@ -59,12 +70,15 @@ __device__ __forceinline__ f32x16 mfma3(const bf16x8 (&a)[2], const bf16x8 (&b)[
     return acc;
 }
 
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
-// position of key kappa (0..31) inside a V^T row: bits 2 and 3 swapped, so that the 8 keys
-// rho(st, half, j) = (j&3) + 8(2 st + (j>>2)) + 4 half of one PV operand sit in 16 contiguous bytes
-__device__ __forceinline__ int v_pos(int kappa) {
-    return (kappa & 0x13) | ((kappa & 4) << 1) | ((kappa & 8) >> 1);
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+// two transposing reads (4 keys x this lane's head dim each) -> one 8-key MFMA operand
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lo4, const unsigned char* hi4) {
+    typedef __attribute__((address_space(3))) short4v* lds_p;
+    const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo4));
+    const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(hi4));
+    const short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, c);
 }
 
 // Distance table -> bf16 hi/lo planes in MFMA-FRAGMENT order.  Every 32-row block of E the kernel touches starts
@@ -95,8 +109,14 @@ __device__ long long e3d_attn_stamps[16][8];
     do {                                                                                                 \
         if (blockIdx.x == 1000 && wid == 1 && lane == 0 && kt < 16) e3d_attn_stamps[kt][slot] = __builtin_readcyclecounter(); \
     } while (0)
+// kernel-level stamps of the same wave: slot 8 + i of row 15 is unused by the tile stamps when L <= 480
+#define KSTAMP(i)                                                                                        \
+    do {                                                                                                 \
+        if (blockIdx.x == 1000 && wid == 1 && lane == 0) e3d_attn_stamps[15][i] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define ASTAMP(slot) do {} while (0)
+#define KSTAMP(i) do {} while (0)
 #endif
 
 template <int W, bool RELKEY>
@@ -104,7 +124,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const bf16x8* __restrict__ e_frag,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq, int Lk,
-    int groups_per_bh, int skip_padded_tiles) {
+    int groups_per_bh, int skip_padded_tiles, float rescale_tau) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = W * 64, NI = 512 / NT;   // float4 staging items per thread, for K and for V
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -113,38 +133,37 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const int grp = blk % groups_per_bh, bh = blk / groups_per_bh, h = bh % nh, b = bh / nh;
     const int q0 = (grp * W + wid) * 32;
     float* ring = reinterpret_cast<float*>(smem_raw + 2 * KV_BUF_B) + wid * RING_F;
+    KSTAMP(0);   // kernel entry
 
-    // Q fragments (B operand of S^T and T^T): row = query, 8 head-dim values per 16-wide k block
-    bf16x8 qf[4][2];
+    // ---- prologue, part 1: ISSUE every global load the prologue needs before consuming any of them.  Kernel-level
+    // stamps showed the prologue at 35 % of a workgroup's life (22 k of 65 k cycles) with its loads in a dependent
+    // chain -- Q -> split, then the key-mask scan (one load per 64 keys, each behind a ballot), then K/V tile 0, then
+    // the first distance block -- i.e. ~6 exposed cold-miss round trips on a CU that has nothing else to run (one
+    // workgroup per CU).  Issued together they cost one.
+    const float* kb_ = k + b * k_bs + h * D;
+    const float* vb_ = v + b * v_bs + h * D;
+    const float* mb = key_mask ? key_mask + (int64_t)b * Lk : nullptr;
+    f32x4 qraw[8];   // Q rows (B operand of S^T and T^T): row = query, 8 head-dim values per 16-wide k block
     {
         const float* qrow = q + b * q_bs + (int64_t)min(q0 + qi, Lq - 1) * q_rs + h * D + 8 * half;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f32x4 lo4 = *reinterpret_cast<const f32x4*>(qrow + 16 * kb);
-            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(qrow + 16 * kb + 4);
-            const float x[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-            split8x2(x, qf[kb][0], qf[kb][1]);
+            qraw[2 * kb] = *reinterpret_cast<const f32x4*>(qrow + 16 * kb);
+            qraw[2 * kb + 1] = *reinterpret_cast<const f32x4*>(qrow + 16 * kb + 4);
         }
     }
+    // key-mask values of keys 64 c + lane, c < 4 (Lk <= 256: every configuration of the reference); unconditional
+    // loads from a valid address (no branch around a load), longer rows finish with the loop below
+    const bool scan_mask = mb && skip_padded_tiles;
+    float mv[4];
+    {
+        const float* mp = mb ? mb : kb_;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mv[c] = mp[min(64 * c + lane, Lk - 1)];
+    }
 
-    const float* kb_ = k + b * k_bs + h * D;
-    const float* vb_ = v + b * v_bs + h * D;
-    const float* mb = key_mask ? key_mask + (int64_t)b * Lk : nullptr;
-
-    // Trailing all-padding key tiles contribute exp(-10000 - m) == 0.0f exactly: stop after the tile
-    // of the last valid key (bit-identical; an all-padding item keeps the full sweep).  Depends on
-    // the batch item only, so every wave of the workgroup runs the same number of barriers.
+    bf16x8 qf[4][2];
     int k_tiles = (Lk + 31) >> 5;
-    if (mb && skip_padded_tiles) {
-        int last = -1;
-        for (int base = 0; base < Lk; base += 64) {
-            const int key = base + lane;
-            const bool valid = key < Lk && mb[key] != 0.f;
-            const unsigned long long bits = __ballot(valid);
-            if (bits) last = base + 63 - __builtin_clzll(bits);
-        }
-        if (last >= 0) k_tiles = (last >> 5) + 1;
-    }
 
     // cooperative staging: item i of this thread = row (f >> 4), head dims 4 (f & 15) .. +3, f = tid + NT i
     // Two register sets when they are small (W >= 4: one or two float4 per operand): tile t+2 is loaded while
@@ -177,16 +196,12 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             *reinterpret_cast<bf16x4*>(buf + row * K_ROW_B + 8 * c4) = hi;
             *reinterpret_cast<bf16x4*>(buf + K_PLANE_B + row * K_ROW_B + 8 * c4) = lo;
             split4x2(sv[SET][i], hi, lo);
-            unsigned char* vt = buf + 2 * K_PLANE_B + (4 * c4) * V_ROW_B + 2 * v_pos(row);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                *reinterpret_cast<__bf16*>(vt + e * V_ROW_B) = hi[e];
-                *reinterpret_cast<__bf16*>(vt + V_PLANE_B + e * V_ROW_B) = lo[e];
-            }
+            *reinterpret_cast<bf16x4*>(buf + 2 * K_PLANE_B + row * V_ROW_B + 8 * c4) = hi;
+            *reinterpret_cast<bf16x4*>(buf + 2 * K_PLANE_B + V_PLANE_B + row * V_ROW_B + 8 * c4) = lo;
         }
         if (tid < 32)
             reinterpret_cast<float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B)[tid] =
-                r0 + tid < Lk ? (1.0f - smask[SET]) * -10000.0f : -INFINITY;
+                r0 + tid < Lk ? (1.0f - smask[SET]) * MASK_BIAS : -INFINITY;
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
@@ -212,16 +227,50 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     };
 
     stage_load(Set0{}, 0);
+    if (RELKEY) e_load(qt + J0);  // rows q0 + P ..: the block "before" key tile 0 fills the upper half of the ring
+
+    // ---- prologue, part 2: consume.  Trailing all-padding key tiles contribute exp(-10000 - m) == 0.0f exactly: stop
+    // after the tile of the last valid key (bit-identical; an all-padding item keeps the full sweep).  Depends on
+    // the batch item only, so every wave of the workgroup runs the same number of barriers.
+    if (scan_mask) {
+        int last = -1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool valid = 64 * c + lane < Lk && mv[c] != 0.f;
+            const unsigned long long bits = __ballot(valid);
+            if (bits) last = 64 * c + 63 - __builtin_clzll(bits);
+        }
+        for (int base = 256; base < Lk; base += 64) {
+            const int key = base + lane;
+            const bool valid = key < Lk && mb[key] != 0.f;
+            const unsigned long long bits = __ballot(valid);
+            if (bits) last = base + 63 - __builtin_clzll(bits);
+        }
+        if (last >= 0) k_tiles = (last >> 5) + 1;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 lo4 = qraw[2 * kb], hi4 = qraw[2 * kb + 1];
+        const float x[8] = {lo4[0] * Q_SCALE, lo4[1] * Q_SCALE, lo4[2] * Q_SCALE, lo4[3] * Q_SCALE,
+                            hi4[0] * Q_SCALE, hi4[1] * Q_SCALE, hi4[2] * Q_SCALE, hi4[3] * Q_SCALE};
+        split8x2(x, qf[kb][0], qf[kb][1]);
+    }
     if (RELKEY) {
-        e_load(qt + J0);          // rows q0 + P ..: the block "before" key tile 0 fills the upper half of the ring
-        const f32x16 t = dot_q(ef);
+        // the block "before" key tile 0 fills the upper half of the ring, the block of tile 0 the lower half (every
+        // later tile's block is computed at the END of the tile before it, see below)
+        f32x16 t = dot_q(ef);
+        e_load(qt - 1 + J0);      // key tile 0: rows q0 - 32 + P ..
 #pragma unroll
         for (int r = 0; r < 16; ++r) ring[(32 + mfma32_row(r, half)) * RING_LD + qi] = t[r];
-        e_load(qt - 1 + J0);      // key tile 0: rows q0 - 32 + P ..
+        t = dot_q(ef);
+        e_load(qt - (k_tiles > 1 ? 1 : 0) - 1 + J0);   // key tile 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ring[mfma32_row(r, half) * RING_LD + qi] = t[r];
     }
     stage_store(Set0{}, 0, smem_raw);
     if (DEEP) stage_load(Set1{}, (k_tiles > 1 ? 1 : 0) * 32);
     __syncthreads();
+    KSTAMP(1);   // prologue done: Q fragments, first K/V tile staged, first distance block in the ring
 
     f32x16 o0, o1;
 #pragma unroll
@@ -262,21 +311,13 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         }
         ASTAMP(2);
         if (RELKEY) {
-            const f32x16 t = dot_q(ef);
-            e_load(qt - kt_next - 1 + J0);   // next tile's block, in flight under the softmax
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ring_w[(32 * PAR + (r & 3) + 8 * (r >> 2)) * RING_LD] = t[r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // rel-key term: the T^T block of this tile was written to the ring at the end of the previous tile (or by
+            // the prologue), so the write -> read round trip of the skew is off the critical path
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 s[r] += PAR ? ring[rd_odd[r]] : ring_e[(27 - ((r & 3) + 8 * (r >> 2))) * RING_LD];
-            __builtin_amdgcn_wave_barrier();
         }
-        // K/V of the next tile: issued only now -- the T MFMAs above wait for the E fragments with an in-order
-        // vmcnt, so any younger load in flight at that point would be waited for as well (stamps: ~1500 cycles)
-        // (two sets: tile t+2 into the set whose tile-t data was stored a tile ago; clamped re-loads at the end)
+        // K/V of tile t+2 into the set whose tile-t data was stored a tile ago (clamped re-loads at the end)
         const int kt_ld = DEEP ? (kt + 2 < k_tiles ? kt + 2 : k_tiles - 1) : kt_next;
         if (PAR == 0) stage_load(Set0{}, kt_ld * 32);
         else stage_load(Set1{}, kt_ld * 32);
@@ -289,28 +330,37 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             const f32x4 bv = *reinterpret_cast<const f32x4*>(kbias + 8 * g + 4 * half);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s[4 * g + j] = s[4 * g + j] * 0.125f + bv[j];
+                s[4 * g + j] += bv[j];              // scores are already in log2 units / sqrt(d) (Q_SCALE)
                 tmax = fmaxf(tmax, s[4 * g + j]);
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = fast_exp(m_run - m_new);
-        m_run = m_new;
+        // deferred rescale: only when some query of the tile outgrows its running maximum by more than 2^TAU
+        // (always on the first tile: m_run = -inf).  Wave-uniform branch; the lanes that do not need it get alpha = 1.
+        const bool grow = tmax > m_run + rescale_tau;
+        if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+            const float m_new = grow ? tmax : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
             psum += s[r];
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        l_run += psum;
         ASTAMP(4);
 
-        // O^T += V^T P^T: two 16-key steps; P^T registers 8 st .. 8 st + 7 are the B operand, the A
-        // operand rows are head dims qi (o0) and 32 + qi (o1) of the transposed V image
-        const unsigned char* vr = buf + 2 * K_PLANE_B + qi * V_ROW_B + 16 * half;
+        // O^T += V^T P^T: two 16-key steps; P^T registers 8 st .. 8 st + 7 are the B operand (keys
+        // rho(8 st + j, half) = 16 st + 8 (j >> 2) + 4 half + (j & 3)); the A operand -- head dims qi (o0) and 32 + qi
+        // (o1) of those keys -- comes from the row-major V image through two transposing reads per fragment:
+        // lane 4 q + p of a 16-lane group addresses key row q, dims 4 p .. 4 p + 3 of the group's 16 dims
+        const unsigned char* vr = buf + 2 * K_PLANE_B + (4 * half + ((lane >> 2) & 3)) * V_ROW_B +
+                                  2 * (16 * ((lane >> 4) & 1) + 4 * (lane & 3));
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             float pv[8];
@@ -318,10 +368,12 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             for (int j = 0; j < 8; ++j) pv[j] = s[8 * st + j];
             bf16x8 pb[2], a0[2], a1[2];
             split8x2(pv, pb[0], pb[1]);
-            a0[0] = *reinterpret_cast<const bf16x8*>(vr + 32 * st);
-            a0[1] = *reinterpret_cast<const bf16x8*>(vr + V_PLANE_B + 32 * st);
-            a1[0] = *reinterpret_cast<const bf16x8*>(vr + 32 * V_ROW_B + 32 * st);
-            a1[1] = *reinterpret_cast<const bf16x8*>(vr + V_PLANE_B + 32 * V_ROW_B + 32 * st);
+            const unsigned char* v0 = vr + 16 * st * V_ROW_B;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a0[pl] = tr_read8(v0 + pl * V_PLANE_B, v0 + pl * V_PLANE_B + 8 * V_ROW_B);
+                a1[pl] = tr_read8(v0 + pl * V_PLANE_B + 64, v0 + pl * V_PLANE_B + 8 * V_ROW_B + 64);
+            }
             o0 = mfma3(a0, pb, o0);
             o1 = mfma3(a1, pb, o1);
         }
@@ -332,6 +384,16 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             else stage_store(Set0{}, kt_next * 32, smem_raw + (PAR ^ 1) * KV_BUF_B);
         }
         ASTAMP(6);
+        if (RELKEY && more) {
+            // T^T block of the NEXT tile (needs only Q and the distance table): 12 MFMAs + the ring writes here, where
+            // the faster waves of the workgroup would otherwise idle at the barrier; its successor's fragments then
+            // have a whole tile to arrive.  Rows 32 (PAR ^ 1) .. + 31 hold the block of tile t - 1, which this tile has
+            // finished reading.
+            const f32x16 t = dot_q(ef);
+            e_load(qt - (kt + 2 < k_tiles ? kt + 2 : k_tiles - 1) - 1 + J0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ring_w[(32 * (PAR ^ 1) + (r & 3) + 8 * (r >> 2)) * RING_LD] = t[r];
+        }
         __syncthreads();
         ASTAMP(7);
     };
@@ -340,6 +402,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         if (kt + 1 < k_tiles) tile(std::integral_constant<int, 1>{}, kt + 1);
     }
 
+    KSTAMP(2);   // key sweep done
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     // transpose the 64 x 32 O^T tile through the ring: out rows leave as 256-byte segments
@@ -363,7 +426,12 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             *reinterpret_cast<f32x4*>(obase + (int64_t)row * (nh * D) + 4 * (lane & 15)) =
                 *reinterpret_cast<const f32x4*>(ring + row * OUT_LD + 4 * (lane & 15));
     }
-    if (lse && half == 0 && q0 + qi < Lq) lse[((int64_t)b * nh + h) * Lq + q0 + qi] = m_run + logf(l_tot);
+    if (lse && half == 0 && q0 + qi < Lq) lse[((int64_t)b * nh + h) * Lq + q0 + qi] = m_run * LN2 + logf(l_tot);
+    KSTAMP(3);   // output stores issued
+#ifdef E3D_ATTN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KSTAMP(4);   // output stores retired
+#endif
 }
 
 template <int W, bool RELKEY>
@@ -375,7 +443,7 @@ int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t
     e3d_allow_lds(lds_ok, attn_coop_kernel<W, RELKEY>, lds);
     const int groups = q_tiles / W;
     hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
-                       k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, nh, Lq, Lk, groups, skip);
+                       k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, nh, Lq, Lk, groups, skip, g_rescale_tau);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (cooperative)");
 }
 
@@ -428,6 +496,14 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
         hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
     return launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh, Lq, Lk,
                             q_tiles, skip, s);
+}
+
+// Diagnostic (tests): threshold of the deferred rescale in log2 units; 0 = raise the maximum on every new one (classic
+// online softmax).  Returns the previous value; a negative argument only queries.
+extern "C" float e3d_attn_rescale_tau(float tau) {
+    const float prev = g_rescale_tau;
+    if (tau >= 0.f) g_rescale_tau = tau;
+    return prev;
 }
 
 #ifdef E3D_ATTN_STAMPS

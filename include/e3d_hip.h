@@ -88,6 +88,12 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
  * accumulation order).  pref < 0 only queries.  Returns the previous value. */
 int e3d_gemm_kernel_select(int pref);
 
+/* Diagnostic (tests/test_kernels_gpu.py): the cooperative bf16x3 attention kernel keeps its running softmax maximum
+ * until a key tile exceeds it by more than 2^tau (default tau = 8, log2 units; results are mathematically
+ * unchanged -- O and the row sum stay relative to the same maximum).  tau = 0 restores the classic online softmax
+ * (rescale on every new maximum).  tau < 0 only queries.  Returns the previous value. */
+float e3d_attn_rescale_tau(float tau);
+
 /* Process-wide switch of the split attention kernels (default 1): stop the key sweep after the tile
  * holding the last valid key of the item.  Trailing all-padding tiles contribute exp(-10000 - m) = 0.0f
  * exactly, so results are bit-identical; 0 restores the dense sweep (timing comparisons).  Returns the

@@ -343,3 +343,52 @@ def test_distance_table_planes_cache_follows_weight_updates(pkg, hip):
         out2 = call(E)
         fresh = call(E.clone())                       # a tensor without cache entry
     assert torch.equal(out2, fresh) and not torch.equal(out2, out1)
+
+
+@pytest.mark.parametrize("relkey", [True, False])
+def test_attention_deferred_rescale_branch_is_forced_and_exact(pkg, hip, relkey):
+    """The cooperative kernel only raises its running softmax maximum when a key tile exceeds it by more than 2^tau
+    (tau = 8): bounded random data never takes that branch after the first tile, so force it -- spiked keys in late
+    tiles (one query jumps at tile 6, another at tile 3 AND again at tile 7, a third by LESS than tau so that it keeps
+    its stale maximum) -- and check (1) against the fp64 statement and (2) tau = 8 against tau = 0 (classic online
+    softmax, rescale on every new maximum): the two must agree to rounding."""
+    B, nh, L, P = 2, 2, 256, 256
+    H = nh * 64
+    qkv = torch.randn(B * L, 3 * H, generator=g(11)) * 0.5
+    q, k = qkv[:, :H], qkv[:, H:2 * H]
+
+    def spike(b, h, query, key, score):      # make (q . k) / 8 of that pair == score
+        qv = q[b * L + query, 64 * h:64 * h + 64]
+        k[b * L + key, 64 * h:64 * h + 64] = qv * (8.0 * score / float(qv @ qv))
+
+    spike(0, 0, 5, 200, 40.0)
+    spike(0, 1, 70, 100, 25.0)
+    spike(0, 1, 70, 250, 45.0)
+    spike(1, 0, 33, 130, 4.0)                # 4 / ln 2 = 5.8 log2 units above ~0: below tau, no rescale
+    E = torch.randn(2 * P - 1, 64, generator=g(12)) * 0.2 if relkey else None
+    mask = torch.ones(B, L)
+    mask[1, 240:] = 0
+    d = qkv.to(DEV)
+    outs = {}
+    for tau in (8.0, 0.0):
+        prev = hip.e3d_attn_rescale_tau(tau)
+        try:
+            outs[tau] = pkg.ops.attention(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),
+                                          dist_emb=None if E is None else E.to(DEV), max_pos=P, want_lse=True,
+                                          mode="bf16x3")
+        finally:
+            hip.e3d_attn_rescale_tau(prev)
+    split = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
+    qd, kd, vd = split(qkv[:, :H]), split(qkv[:, H:2 * H]), split(qkv[:, 2 * H:])
+    ref = ref_attention(qd, kd, vd, mask.double(), None if E is None else E.double(), P)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * L, H).float()
+    s = qd @ kd.transpose(-1, -2)
+    if E is not None:
+        s = s + obert.relkey_scores_literal(qd, E.double(), P)
+    s = s / 8.0 + ((1.0 - mask.double()) * -10000.0)[:, None, None, :]
+    lse_ref = torch.logsumexp(s, -1).float()
+    for tau, (got, lse) in outs.items():
+        assert rel_err(got, ref) < 1e-4, tau
+        assert rel_err(lse, lse_ref) < 1e-4, tau
+        assert (got[5].cpu() - ref[5]).abs().max() < 1e-4 * ref.abs().max()      # the spiked query itself
+    assert rel_err(outs[8.0][0], outs[0.0][0]) < 1e-5 and rel_err(outs[8.0][1], outs[0.0][1]) < 1e-5   # measured 4e-6

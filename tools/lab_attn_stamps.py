@@ -29,3 +29,6 @@ names = ["start", "stage loads issued", "S mfma issued", "T + ring skew done", "
 for kt in range(L // 32):
     row = [buf[kt * 8 + s] for s in range(8)]
     print(f"kt {kt}: " + "  ".join(f"{names[i]}=+{row[i] - row[i - 1]}" for i in range(1, 8)) + f"  | total {row[7] - row[0]}")
+k = [buf[15 * 8 + i] for i in range(5)]
+print(f"kernel-level (workgroup 1000, wave 1), cycles: prologue {k[1] - k[0]}  key sweep {k[2] - k[1]}  epilogue to stores issued "
+      f"{k[3] - k[2]}  stores retired +{k[4] - k[3]}  | total {k[4] - k[0]}")
