@@ -30,6 +30,24 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// element type of the two split terms: __bf16 (bf16x3) or _Float16 (f16x3: 11 + 11 bits per operand, for operands
+// inside the fp16 range -- Q is pre-scaled by 0.18, P <= 2^tau, K / V are projection outputs, E a parameter table)
+template <typename E> struct AV;
+template <> struct AV<__bf16> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <> struct AV<_Float16> { typedef f16x8 x8; typedef f16x4 x4; };
+template <typename X> struct Elem;
+template <> struct Elem<bf16x8> { typedef __bf16 type; };
+template <> struct Elem<bf16x4> { typedef __bf16 type; };
+template <> struct Elem<f16x8> { typedef _Float16 type; };
+template <> struct Elem<f16x4> { typedef _Float16 type; };
+__device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 constexpr int D = 64;
 constexpr int RING_LD = 34;
@@ -44,41 +62,47 @@ constexpr float MASK_BIAS = -10000.0f * LOG2E;
 float g_rescale_tau = 8.0f;                   // raise the running maximum only past m + 8 (probabilities <= 2^8); e3d_attn_rescale_tau
 constexpr int KV_BUF_B = 2 * K_PLANE_B + 2 * V_PLANE_B + 128;   // + 32 floats of key bias
 
-__device__ __forceinline__ void split4x2(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+template <typename X4>
+__device__ __forceinline__ void split4x2(const f32x4 v, X4& hi, X4& lo) {
+    typedef typename Elem<X4>::type E;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const __bf16 p = (__bf16)v[j];
+        const E p = (E)v[j];
         hi[j] = p;
-        lo[j] = (__bf16)(v[j] - (float)p);
+        lo[j] = (E)(v[j] - (float)p);
     }
 }
 
-__device__ __forceinline__ void split8x2(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+template <typename X8>
+__device__ __forceinline__ void split8x2(const float (&x)[8], X8& hi, X8& lo) {
+    typedef typename Elem<X8>::type E;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 p = (__bf16)x[j];
+        const E p = (E)x[j];
         hi[j] = p;
-        lo[j] = (__bf16)(x[j] - (float)p);
+        lo[j] = (E)(x[j] - (float)p);
     }
 }
 
 // acc += a.b from the three significant cross terms, smallest first ([0] = hi, [1] = lo)
-__device__ __forceinline__ f32x16 mfma3(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+template <typename X8>
+__device__ __forceinline__ f32x16 mfma3(const X8 (&a)[2], const X8 (&b)[2], f32x16 acc) {
+    acc = mma16(a[0], b[1], acc);
+    acc = mma16(a[1], b[0], acc);
+    acc = mma16(a[0], b[0], acc);
     return acc;
 }
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef short short8v __attribute__((ext_vector_type(8)));
 // two transposing reads (4 keys x this lane's head dim each) -> one 8-key MFMA operand
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lo4, const unsigned char* hi4) {
+template <typename X8>
+__device__ __forceinline__ X8 tr_read8(const unsigned char* lo4, const unsigned char* hi4) {
     typedef __attribute__((address_space(3))) short4v* lds_p;
     const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo4));
     const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(hi4));
     const short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, c);
+    return __builtin_bit_cast(X8, c);
 }
 
 // Distance table -> bf16 hi/lo planes in MFMA-FRAGMENT order.  Every 32-row block of E the kernel touches starts
@@ -86,19 +110,20 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* lo4, const unsig
 // fragments of block j = m + J0 are laid out as [j][plane][kb][lane] x 16 bytes: a wave's E load is then 8
 // fully coalesced 1-KB reads instead of 8 reads of 64 scattered 16-byte pieces (measured: 17 % of the kernel).
 // Rows outside [0, 2P-2] (never paired with a valid (query, key)) are clamped.
-__global__ __launch_bounds__(256) void e_fragments_kernel(const float* __restrict__ e, bf16x8* __restrict__ frag, int P,
-                                                          int J0, int n_items) {
+template <typename E>
+__global__ __launch_bounds__(256) void e_fragments_kernel(const float* __restrict__ e, typename AV<E>::x8* __restrict__ frag,
+                                                          int P, int J0, int n_items) {
     const int i = blockIdx.x * 256 + threadIdx.x;   // item = ((j * 2 + plane) * 4 + kb) * 64 + lane
     if (i >= n_items) return;
     const int lane = i & 63, kb = (i >> 6) & 3, plane = (i >> 8) & 1, j = i >> 9;
     const int row = min(max(P + 32 * (j - J0) + (lane & 31), 0), 2 * P - 2);
     const float* src = e + row * D + 16 * kb + 8 * (lane >> 5);
-    bf16x8 out;
+    typename AV<E>::x8 out;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const float v = src[t];
-        const __bf16 hi = (__bf16)v;
-        out[t] = plane ? (__bf16)(v - (float)hi) : hi;
+        const E hi = (E)v;
+        out[t] = plane ? (E)(v - (float)hi) : hi;
     }
     frag[i] = out;
 }
@@ -119,12 +144,14 @@ __device__ long long e3d_attn_stamps[16][8];
 #define KSTAMP(i) do {} while (0)
 #endif
 
-template <int W, bool RELKEY>
+template <int W, bool RELKEY, typename E>
 __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
-    int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const bf16x8* __restrict__ e_frag,
+    int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const typename AV<E>::x8* __restrict__ e_frag,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq, int Lk,
     int groups_per_bh, int skip_padded_tiles, float rescale_tau) {
+    typedef typename AV<E>::x8 bf16x8;   // (names kept from the bf16 form: 8 / 4 split terms of type E)
+    typedef typename AV<E>::x4 bf16x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = W * 64, NI = 512 / NT;   // float4 staging items per thread, for K and for V
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -371,8 +398,8 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             const unsigned char* v0 = vr + 16 * st * V_ROW_B;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                a0[pl] = tr_read8(v0 + pl * V_PLANE_B, v0 + pl * V_PLANE_B + 8 * V_ROW_B);
-                a1[pl] = tr_read8(v0 + pl * V_PLANE_B + 64, v0 + pl * V_PLANE_B + 8 * V_ROW_B + 64);
+                a0[pl] = tr_read8<bf16x8>(v0 + pl * V_PLANE_B, v0 + pl * V_PLANE_B + 8 * V_ROW_B);
+                a1[pl] = tr_read8<bf16x8>(v0 + pl * V_PLANE_B + 64, v0 + pl * V_PLANE_B + 8 * V_ROW_B + 64);
             }
             o0 = mfma3(a0, pb, o0);
             o1 = mfma3(a1, pb, o1);
@@ -434,27 +461,27 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
 #endif
 }
 
-template <int W, bool RELKEY>
+template <int W, bool RELKEY, typename E>
 int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
-             int64_t v_bs, int64_t v_rs, const bf16x8* e_frag, int P, const float* key_mask,
+             int64_t v_bs, int64_t v_rs, const void* e_frag, int P, const float* key_mask,
              float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip, hipStream_t s) {
     const size_t lds = 2 * KV_BUF_B + (size_t)W * RING_F * sizeof(float);
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, attn_coop_kernel<W, RELKEY>, lds);
+    e3d_allow_lds(lds_ok, attn_coop_kernel<W, RELKEY, E>, lds);
     const int groups = q_tiles / W;
-    hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
-                       k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, nh, Lq, Lk, groups, skip, g_rescale_tau);
+    hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY, E>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
+                       k_rs, v, v_bs, v_rs, reinterpret_cast<const typename AV<E>::x8*>(e_frag), P, key_mask, out, lse, nh, Lq, Lk, groups, skip, g_rescale_tau);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (cooperative)");
 }
 
-template <bool RELKEY>
+template <bool RELKEY, typename E>
 int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
-               const float* v, int64_t v_bs, int64_t v_rs, const bf16x8* e_frag, int P,
+               const float* v, int64_t v_bs, int64_t v_rs, const void* e_frag, int P,
                const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip,
                hipStream_t s) {
 #define E3D_COOP_CASE(w)                                                                                          \
     case w:                                                                                                       \
-        return launch_w<w, RELKEY>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, B, nh, \
+        return launch_w<w, RELKEY, E>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, B, nh, \
                                    Lq, Lk, q_tiles, skip, s)
     switch (W) {
         E3D_COOP_CASE(8);
@@ -468,9 +495,8 @@ int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k
 
 }  // namespace
 
-// bf16x3 attention, cooperative kernel.  Same contract as e3d_relkey_attn_fwd_split with terms = 3
-// (arguments already validated there); v rows must be 16-byte aligned (v_rs % 4 == 0).
-int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
+template <typename E>
+static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
                          void* e_scratch, int e_ready, hipStream_t s) {
@@ -483,19 +509,32 @@ int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float
     int W = q_tiles % 8 == 0 ? 8 : (q_tiles % 4 == 0 ? 4 : (q_tiles % 2 == 0 ? 2 : 1));
     while (W > w_max && W > 1) W >>= 1;
     if (!dist_emb)
-        return launch_any<false>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh, Lq,
-                                 Lk, q_tiles, skip, s);
-    // distance table -> fragment-order bf16 planes in the caller's scratch (e3d_attn_scratch_bytes(Lk) bytes)
+        return launch_any<false, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh,
+                                    Lq, Lk, q_tiles, skip, s);
+    // distance table -> fragment-order hi / lo planes in the caller's scratch (e3d_attn_scratch_bytes(Lk) bytes)
     if (!e_scratch) {
         e3d_set_error("attn_coop: rel-key attention needs the caller's scratch for the distance-table planes");
         return -1;
     }
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
-    bf16x8* planes = reinterpret_cast<bf16x8*>(e_scratch);
-    if (!e_ready)   // e_ready: the caller kept the planes of this (dist_emb, Lk) from an earlier call
-        hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, planes, P, J0, n_items);
-    return launch_any<true>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, planes, P, key_mask, out, lse, B, nh, Lq, Lk,
-                            q_tiles, skip, s);
+    if (!e_ready)   // e_ready: the caller kept the planes of this (dist_emb, Lk, terms) from an earlier call
+        hipLaunchKernelGGL(e_fragments_kernel<E>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
+                           reinterpret_cast<typename AV<E>::x8*>(e_scratch), P, J0, n_items);
+    return launch_any<true, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_scratch, P, key_mask, out, lse, B, nh, Lq,
+                               Lk, q_tiles, skip, s);
+}
+
+// bf16x3 / f16x3 attention, cooperative kernel.  Same contract as e3d_relkey_attn_fwd_split with terms = 3 / 19
+// (arguments already validated there); v rows must be 16-byte aligned (v_rs % 4 == 0).
+int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
+                         const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
+                         const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
+                         void* e_scratch, int e_ready, int f16, hipStream_t s) {
+    if (f16)
+        return coop_launch_t<_Float16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq,
+                                       Lk, skip, e_scratch, e_ready, s);
+    return coop_launch_t<__bf16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk,
+                                 skip, e_scratch, e_ready, s);
 }
 
 // Diagnostic (tests): threshold of the deferred rescale in log2 units; 0 = raise the maximum on every new one (classic
@@ -513,10 +552,14 @@ extern "C" int e3d_debug_read_attn_stamps(long long* host_out) {
 #endif
 
 // the pre-pass alone: fragment-order planes of dist_emb for key length Lk into ``scratch``
-int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, hipStream_t s) {
+int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, hipStream_t s) {
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
-    hipLaunchKernelGGL(e_fragments_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
-                       reinterpret_cast<bf16x8*>(scratch), P, J0, n_items);
+    if (f16)
+        hipLaunchKernelGGL(e_fragments_kernel<_Float16>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
+                           reinterpret_cast<f16x8*>(scratch), P, J0, n_items);
+    else
+        hipLaunchKernelGGL(e_fragments_kernel<__bf16>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
+                           reinterpret_cast<bf16x8*>(scratch), P, J0, n_items);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (distance-table planes)");
 }
 

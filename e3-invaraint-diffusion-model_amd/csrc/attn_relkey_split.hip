@@ -342,7 +342,8 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
                 "attn_split: strides must keep 16B (q,k) / 8B (v) alignment");
     E3D_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                     ((uintptr_t)out % 16) == 0, "attn_split: pointers must be 16B aligned");
-    E3D_REQUIRE(terms == 3 || terms == 6, "attn_split: terms must be 3 or 6 (got %d)", terms);
+    E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "attn_split: terms must be 3, 6 or 19 (got %d)", terms);
+    const int f16 = terms == E3D_TERMS_F16X3;
     E3D_REQUIRE((int64_t)Lk * k_rs < (1ll << 30) && (int64_t)Lk * v_rs < (1ll << 30),
                 "attn_split: one batch item's K/V slab must stay below 2^30 elements (32-bit lane offsets)");
     if (dist_emb) {
@@ -353,7 +354,7 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     hipStream_t s = (hipStream_t)stream;
     if (dist_emb && e_scratch && !e_scratch_ready) {
         // whichever kernel serves this call, a scratch handed in is valid afterwards (callers cache it)
-        const int rc = e3d_attn_fill_planes(dist_emb, P, Lk, e_scratch, s);
+        const int rc = e3d_attn_fill_planes(dist_emb, P, Lk, e_scratch, f16, s);
         if (rc) return rc;
         e_scratch_ready = 1;
     }
@@ -371,10 +372,11 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     // two-wave groups (q_tiles % 4 != 0) measured slower than the per-wave kernel: too little sharing per barrier
     // the cooperative kernel reads the distance table as fragment-order bf16 planes from a CALLER-provided scratch
     // (e3d_attn_scratch_bytes); without one the per-wave kernel below serves the call -- the library never allocates
-    if (terms == 3 && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1) &&
+    if ((terms == 3 || f16) && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1) &&
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, g_skip_padded, e_scratch, e_scratch_ready, s);
+                                    Lq, Lk, g_skip_padded, e_scratch, e_scratch_ready, f16, s);
+    // f16x3 exists in the cooperative kernel only: other shapes run the fp32-grade bf16x6 per-wave kernel
     if (terms == 3)
         return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
     return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);

@@ -17,7 +17,7 @@ void e3d_set_error(const char* fmt, ...);
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         void* e_scratch, int e_ready, hipStream_t s);
+                         void* e_scratch, int e_ready, int f16, hipStream_t s);
 
 #define E3D_REQUIRE(cond, ...)       \
     do {                             \
@@ -125,7 +125,7 @@ __device__ __forceinline__ uint64_t e3d_attn_drop_idx4(int bh, int Lq, int Lk, i
     return ((uint64_t)bh * Lq + q) * (uint64_t)((Lk + 3) >> 2) + (uint64_t)(key0 >> 2);
 }
 
-int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, hipStream_t s);
+int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, hipStream_t s);
 
 // attn_bwd_split.hip: launches A and B of the attention backward in bf16x3 arithmetic (internal)
 int e3d_attn_bwd_split_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,

@@ -26,6 +26,22 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Element type of the split terms: __bf16 (8 significant bits per term, fp32 exponent range: bf16x3 / bf16x6) or
+// _Float16 (11 bits per term: TWO terms carry 22 bits, so the three cross products a0 b0 + a0 b1 + a1 b0 are
+// ~2^-21 accurate -- fp32 grade at the cost of bf16x3 -- for operands inside the fp16 range: |x| < 65504, and
+// elements below 2^-14 keep an absolute error of 2^-25 instead of a relative one: "f16x3").
+template <typename E> struct Vec;
+template <> struct Vec<__bf16> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <> struct Vec<_Float16> { typedef f16x8 x8; typedef f16x4 x4; };
+__device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 constexpr int BN = 128, BK = 32;
 // LDS rows are 64 bytes (32 bf16) unpadded, with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3: the 16 lanes
@@ -33,14 +49,14 @@ constexpr int BN = 128, BK = 32;
 constexpr int ROW_B = 64;
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROW_B + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int NS>
-__device__ __forceinline__ void split4(const f32x4 v, bf16x4 (&parts)[NS]) {
+template <int NS, typename E>
+__device__ __forceinline__ void split4(const f32x4 v, typename Vec<E>::x4 (&parts)[NS]) {
     f32x4 r = v;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const __bf16 p = (__bf16)r[j];
+            const E p = (E)r[j];
             parts[s][j] = p;
             r[j] -= (float)p;
         }
@@ -103,28 +119,28 @@ struct Stager {
     }
     // ``k0`` = first k of the k-tile the registers hold: K-major items zero their reduction tail (k >= K, token
     // counts that are not a multiple of 32) here, away from the loads, so that no load result is needed early
-    template <int NS>
+    template <int NS, typename E>
     __device__ __forceinline__ void store_item(int i, const f32x4& vin, unsigned char* img, int part_bytes, int k0, int K) const {
         f32x4 v = vin;
         if (KMAJ) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = k0 + kbase[i] + j < K ? v[j] : 0.f;
         }
-        bf16x4 p[NS];
-        split4<NS>(v, p);
+        typename Vec<E>::x4 p[NS];
+        split4<NS, E>(v, p);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(img + s * part_bytes + off[i]) = p[s];
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(img + s * part_bytes + off[i]) = p[s];
     }
-    template <int NS>
+    template <int NS, typename E>
     __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes, int k0, int K) const {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) store_item<NS>(i, v[i], img, part_bytes, k0, K);
+        for (int i = 0; i < NV; ++i) store_item<NS, E>(i, v[i], img, part_bytes, k0, K);
     }
 };
 
 // WM = waves along M: 4 -> 256x128 tile, 512 threads; 2 -> 128x128 tile, 256 threads (used for grids of a few
 // tiles only: it halves the padded rows of an M = 64 problem; at M = 4096 it measured 25 % slower than WM = 4).
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
 __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
@@ -166,8 +182,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
     f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
     sa.load(ra, k_begin, K);
     sb.load(rb, k_begin, K);
-    sa.template store<NS>(ra, smem_raw, A_BYTES, k_begin, K);
-    sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin, K);
+    sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin, K);
+    sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin, K);
     __syncthreads();
 
     const int nk = (K - k_begin + BK - 1) / BK;
@@ -195,15 +211,15 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[NS][2], fb[NS][2];
+            typename Vec<E>::x8 fa[NS][2], fb[NS][2];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    fa[s][m] = *reinterpret_cast<const bf16x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
+                    fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    fb[s][n] = *reinterpret_cast<const bf16x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
+                    fb[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -212,13 +228,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
 #pragma unroll
                     for (int i = 0; i < NA_; ++i)
                         if (i * 4 / NA_ == g) {
-                            sa.template store_item<NS>(i, ra[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
+                            sa.template store_item<NS, E>(i, ra[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
                             sa.load_item(i, ra[i], k2, K);
                         }
 #pragma unroll
                     for (int i = 0; i < NB_; ++i)
                         if (i * 4 / NB_ == g) {
-                            sb.template store_item<NS>(i, rb[i], nxt + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
+                            sb.template store_item<NS, E>(i, rb[i], nxt + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
                             sb.load_item(i, rb[i], k2, K);
                         }
                 }
@@ -226,13 +242,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
                 for (int n = 0; n < 2; ++n) {
                     // smallest terms first
                     if (NS == 3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[NS - 1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = mma16(fa[1][m], fb[1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[0][m], fb[NS - 1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[NS - 1][m], fb[0][n], acc[m][n]);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
+                    acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                 }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
             }
@@ -243,8 +259,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
         } else {
             __syncthreads();  // everyone done reading the single buffer
             if (more) {
-                sa.template store<NS>(ra, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
-                sb.template store<NS>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
+                sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
+                sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
             }
             __syncthreads();
         }
@@ -305,7 +321,7 @@ __device__ long long e3d_stamps[2][32][8];
 // one register item of tile t+1 (loaded during iteration t-1), then the re-issue of that item's
 // global load for tile t+2 (one register set, distance 2), so loads, VALU and LDS writes all run
 // under the MFMAs of the other wave of the SIMD.
-template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE>
+template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE, typename E>
 __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const float* __restrict__ A, int64_t lda,
                                                                         const float* __restrict__ W,
                                                                         const float* __restrict__ bias,
@@ -356,11 +372,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
     f32x4 rg[NI];
     auto item_load = [&](int i, int kt) { rg[i] = *reinterpret_cast<const f32x4*>(src[i] + kt * BK); };
     auto item_store = [&](int i, unsigned char* buf) {
-        bf16x4 p[NS];
-        split4<NS>(rg[i], p);
+        typename Vec<E>::x4 p[NS];
+        split4<NS, E>(rg[i], p);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            *reinterpret_cast<bf16x4*>(buf + s * (i < NA ? A_BYTES : B_BYTES) + dst[i]) = p[s];
+            *reinterpret_cast<typename Vec<E>::x4*>(buf + s * (i < NA ? A_BYTES : B_BYTES) + dst[i]) = p[s];
     };
 
     STAMP_K(1);   // addressing done
@@ -400,16 +416,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
         const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[NS][4], fb[NS][2];
+            typename Vec<E>::x8 fa[NS][4], fb[NS][2];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    fb[s][n] = *reinterpret_cast<const bf16x8*>(base + NS * A_BYTES + s * B_BYTES +
+                    fb[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(base + NS * A_BYTES + s * B_BYTES +
                                                                 swz_off(b_row[n], 2 * ks + half));
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * A_BYTES + swz_off(a_row[m], 2 * ks + half));
+                    fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(base + s * A_BYTES + swz_off(a_row[m], 2 * ks + half));
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -425,13 +441,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     if (NS == 3) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[NS - 1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[NS - 1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = mma16(fa[1][m], fb[1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[0][m], fb[NS - 1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[NS - 1][m], fb[0][n], acc[m][n]);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
+                    acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                 }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
             }
@@ -466,12 +482,13 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
     }
 
     STAMP_K(3);   // k loop done
+    // (m outer, n inner: the other loop order -- one bias load per column block -- costs 36-84 B/lane of scratch)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = col0 + wc * 64 + n * 32 + l31;
-        const float bv = bias ? bias[col] : 0.f;
+    for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int n = 0; n < 2; ++n) {
+            const int col = col0 + wc * 64 + n * 32 + l31;
+            const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + wr * 128 + m * 32 + mfma32_row(r, half);
@@ -505,7 +522,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 #define E3D_STORE_OUT(ptr, val) (*(ptr) = (val))
 #endif
 
-template <int ACT>
+template <int ACT, typename E>
 __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ W,
                                                                  const float* __restrict__ bias,
@@ -560,10 +577,10 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 #ifdef E3D_LAB_NO_STAGE
         if (K > 0) return;
 #endif
-        bf16x4 p[NS];
-        split4<NS>(rg[i], p);
+        typename Vec<E>::x4 p[NS];
+        split4<NS, E>(rg[i], p);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(buf + s * T_BYTES + dst[i]) = p[s];
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(buf + s * T_BYTES + dst[i]) = p[s];
     };
 
     cursor_bases();
@@ -598,16 +615,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
             unsigned char* next = smem_raw + (cur ^ 1) * BUF_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[NS][4], fb[NS][2];
+                typename Vec<E>::x8 fa[NS][4], fb[NS][2];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        fb[s][n] = *reinterpret_cast<const bf16x8*>(base + (NS + s) * T_BYTES +
+                        fb[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(base + (NS + s) * T_BYTES +
                                                                     swz_off(b_row[n], 2 * ks + half));
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        fa[s][m] = *reinterpret_cast<const bf16x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
+                        fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
@@ -616,9 +633,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                     item_load(g);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -628,14 +645,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
             cur ^= 1;
         }
 
+        // epilogue: rows m * 32 .. of this wave's 128 x 64 part, one 32-row group at a time (this loop order keeps the
+        // kernel free of scratch spills: the n-outer order with one bias load per column block cost 12-36 B/lane)
         const int lid = xcd_remap(tile, total);
         const int row0 = (lid / tiles_n) * BT, col0 = (lid % tiles_n) * BT;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int col = col0 + wc * 64 + n * 32 + l31;
-            const float bv = bias ? bias[col] : 0.f;
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int n = 0; n < 2; ++n) {
+                const int col = col0 + wc * 64 + n * 32 + l31;
+                const float bv = bias ? bias[col] : 0.f;
                 float* o = out + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * ldc + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -652,16 +671,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
     }
 }
 
-template <int ACT>
+template <int ACT, typename E>
 int launch256p(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
                int K, hipStream_t s) {
     const int tiles_m = M / BT, tiles_n = N / BT;
     constexpr size_t lds = 2 * 2 * 2 * BT * ROW64;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split256p_kernel<ACT>, lds);
+    e3d_allow_lds(lds_ok, gemm_split256p_kernel<ACT, E>, lds);
     const int n_cu = e3d_cu_count();
     const int total = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_split256p_kernel<ACT>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias,
+    hipLaunchKernelGGL((gemm_split256p_kernel<ACT, E>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias,
                        out, ldc, N, K, tiles_m, tiles_n);
     return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
 }
@@ -669,20 +688,20 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
 int g_tile_pref = -1;  // E3D_GEMM_TILE (A/B runs): 0 = 256x128 (8 waves of 64x64) for every shape, 1 = 256x256 classic
                        // loop, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
 
-template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE = false>
+template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE, typename E>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
               int K, hipStream_t s) {
     constexpr int TM = WR * 128, TN = WC * 64;
     const int tiles_m = (M + TM - 1) / TM, tiles_n = N / TN;
     const size_t lds = (size_t)NBUF * NS * (TM + TN) * ROW64;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>, lds);
-    hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE>), dim3(tiles_m * tiles_n), dim3(WR * WC * 64), lds, s,
+    e3d_allow_lds(lds_ok, gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE, E>, lds);
+    hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE, E>), dim3(tiles_m * tiles_n), dim3(WR * WC * 64), lds, s,
                        A, lda, W, bias, out, ldc, M, N, K, tiles_m, tiles_n);
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s);
 
@@ -696,23 +715,25 @@ int p_min() {
     return v;
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, typename E>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
            int M, int N, int K, hipStream_t s) {
     if (g_tile_pref < 0) {
         const char* e = getenv("E3D_GEMM_TILE");
         g_tile_pref = e ? atoi(e) : 4;
     }
-    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && NS == 2 && K >= 2 * BK &&
-        lda < (1 << 22) && (int64_t)(M / BT) * (N / BT) >= p_min()) {
-        return launch256p<ACT>(A, lda, B, bias, out, ldc, M, N, K, s);
+    if constexpr (!A_KMAJ && !B_KMAJ) {
+        if constexpr (NS == 2) {
+            if (N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && K >= 2 * BK && lda < (1 << 22) &&
+                (int64_t)(M / BT) * (N / BT) >= p_min())
+                return launch256p<ACT, E>(A, lda, B, bias, out, ldc, M, N, K, s);
+            if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
+                return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, s);
+        }
+        if (N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
+            (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
+            return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, s);
     }
-    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 3 && NS == 2 &&
-        (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
-        return launch256<NS, ACT, 2, 4, 2, true>(A, lda, B, bias, out, ldc, M, N, K, s);
-    if (!A_KMAJ && !B_KMAJ && N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
-        (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
-        return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1)>(A, lda, B, bias, out, ldc, M, N, K, s);
     // a handful of 256-row tiles (single-pocket sampling): 128-row tiles
     static int wm_pref = -1;   // E3D_GEMM_WM = 2 / 4 forces a form (experiments)
     if (wm_pref < 0) {
@@ -722,11 +743,11 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     const int tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
     // (measured: a win only for very small grids -- single-pocket sampling; at M = 4096 the 256-row form is 25 % faster)
     if (NS == 2 && (wm_pref == 2 || (wm_pref == 0 && tiles256 < 128 && !A_KMAJ && !B_KMAJ)))
-        return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+        return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s) {
     constexpr int BM = WM * 64;
@@ -734,7 +755,7 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
     constexpr int NBUF = NS == 2 ? 2 : 1;
     const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>, lds);
+    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, E>, lds);
     // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count
     int splits = 1;
     if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 32 * WM && K >= 1024) {
@@ -754,19 +775,19 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
             return (int)e;
         }
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM>), dim3(tiles_m * tiles_n, splits), dim3(WM * 128),
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, E>), dim3(tiles_m * tiles_n, splits), dim3(WM * 128),
                        lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
     return e3d_launch_status("e3d_gemm_f32_split");
 }
 
-template <int NS>
+template <int NS, typename E>
 int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
              const float* bias, float* out, int64_t ldc, int M, int N, int K, hipStream_t s) {
     if (!a_kmaj && !b_kmaj) {
         switch (act) {
-            case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-            case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-            case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU, false, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+            case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+            case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+            case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
         }
         e3d_set_error("gemm_split: unknown activation %d", act);
         return -1;
@@ -775,9 +796,10 @@ int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, con
         e3d_set_error("gemm_split: activations are only fused for the forward (K-contiguous) layout");
         return -1;
     }
-    if (!a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, false, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-    if (a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, true, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-    return launch<NS, E3D_ACT_NONE, true, false>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    // K-major operand layouts (the training GEMMs) exist for the bf16 terms only
+    if (!a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, false, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    if (a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, true, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return launch<NS, E3D_ACT_NONE, true, false, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
 }  // namespace
@@ -804,7 +826,7 @@ extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kma
                                           void* stream) {
     E3D_REQUIRE(A && B && out, "gemm_split: null pointer");
     E3D_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_split: bad shape M=%d N=%d K=%d", M, N, K);
-    E3D_REQUIRE(terms == 3 || terms == 6, "gemm_split: terms must be 3 or 6 (got %d)", terms);
+    E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "gemm_split: terms must be 3, 6 or 19 (got %d)", terms);
     E3D_REQUIRE(ldc >= N, "gemm_split: ldc=%lld < N=%d", (long long)ldc, N);
     if (!a_kmajor) E3D_REQUIRE(lda >= K && lda % 4 == 0 && K % BK == 0 && ((uintptr_t)A % 16) == 0,
                                "gemm_split: K-contiguous A needs K%%32==0, lda%%4==0, 16B alignment (K=%d lda=%lld)", K, (long long)lda);
@@ -813,8 +835,13 @@ extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kma
                                "gemm_split: K-contiguous B needs K%%32==0, ldb%%4==0, 16B alignment (K=%d ldb=%lld)", K, (long long)ldb);
     else E3D_REQUIRE(ldb >= N, "gemm_split: K-major B needs ldb >= N");
     hipStream_t s = (hipStream_t)stream;
-    if (terms == 3) return dispatch<2>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-    return dispatch<3>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    if (terms == 3) return dispatch<2, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    if (terms == E3D_TERMS_F16X3) {
+        // fp16 terms exist for the forward layout; a K-major operand (training GEMMs) runs the fp32-grade bf16x6 form
+        if (!a_kmajor && !b_kmajor) return dispatch<2, _Float16>(act, false, false, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+        return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    }
+    return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
 extern "C" int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W,

@@ -117,7 +117,10 @@ except ImportError:      # very old torch: training.fit() bumps the generation a
 # GEMM arithmetic: "f32" = exact fp32 MFMA; "bf16x3" / "bf16x6" = fp32 operands split into 2 / 3
 # bf16 terms on the bf16 matrix cores with fp32 accumulation (gemm_split.hip).  bf16x6 is fp32-grade
 # (4e-7 end-to-end vs 1.8e-6 for fp32 itself), bf16x3 ~2.6e-5 end-to-end (tolerance 1e-4).
-GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6}
+# "f16x3" = 2 fp16 terms (11 + 11 bits), 3 cross products: fp32-grade accuracy at the cost of bf16x3 for operands
+# inside the fp16 range (|x| < 65504 -- larger values give inf/NaN, loudly; include/e3d_hip.h E3D_TERMS_F16X3);
+# forward GEMMs and the cooperative attention kernel, every other path of that mode runs bf16x6 / fp32 kernels.
+GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6, "f16x3": 19}
 GEMM_MODE = os.environ.get("E3D_GEMM_MODE", "bf16x3")
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"E3D_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {GEMM_MODE!r}")
@@ -238,13 +241,13 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
                 # inference (grad disabled): the planes are kept across calls, keyed by the tensor's version / storage
                 infer = not torch.is_grad_enabled()
                 ent = getattr(dist_emb, "_e3d_planes", None) if infer else None
-                if ent is not None and ent[0] == weight_key(dist_emb) + (Lk,):
+                if ent is not None and ent[0] == weight_key(dist_emb) + (Lk, terms):
                     scratch, ready = ent[1], 1
                 else:
                     scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
                     if infer and not torch.cuda.is_current_stream_capturing():
                         try:
-                            dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk,), scratch)
+                            dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk, terms), scratch)
                         except AttributeError:
                             pass
             p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)

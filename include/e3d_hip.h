@@ -26,6 +26,17 @@ extern "C" {
 
 #define E3D_ABI_VERSION 1
 
+/* ``terms`` of the split-operand entry points: how an fp32 operand enters the 16-bit matrix cores.
+ *   3  (bf16x3): 2 bf16 terms, 3 cross products, ~2^-17 per product, fp32 exponent range;
+ *   6  (bf16x6): 3 bf16 terms, 6 cross products, ~2^-24 (fp32 grade), fp32 exponent range;
+ *   19 (f16x3):  2 fp16 terms (11 bits each), 3 cross products, ~2^-21 per product -- fp32 grade at the cost of
+ *                bf16x3 -- for operands inside the fp16 range: |x| < 65504 (larger values become inf, i.e. the result is
+ *                NaN/inf, never silently wrong), elements below 2^-14 carry an ABSOLUTE error of 2^-25.  Forward
+ *                (K-contiguous) GEMM layout and the cooperative attention kernel; other paths run bf16x6. */
+#define E3D_TERMS_BF16X3 3
+#define E3D_TERMS_BF16X6 6
+#define E3D_TERMS_F16X3 19
+
 #define E3D_ACT_NONE 0
 #define E3D_ACT_GELU 1 /* exact erf GELU: transformers get_activation("gelu"), nn.GELU() */
 #define E3D_ACT_SILU 2 /* nn.SiLU in SELayer.adaLN_modulation, structure_model/model.py:34 */

@@ -96,7 +96,7 @@ def report_grad_errors(tag, errs, capsys):
 
 
 # ------------------------------------------------------------------------------------ config 1
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])
 def test_config1_single_pocket_64_residues_50_steps(pkg, hip, mode, capsys):
     """BASELINE configs[0] at its full size on the GPU: ONE 64-residue pocket, the full 12+12-layer model, all 50
     reverse steps of a T=50 schedule, teacher-forced against the CPU oracle's chain (each step restarted from the
@@ -365,12 +365,13 @@ def test_config5_joint_chain_128_pockets_x128(pkg, hip, capsys):
 # ------------------------------------------------------------------------------------ bf16x3 margin (item 1b)
 @pytest.mark.parametrize("regime,scale", [("random-init", 1.0), ("weights x2, gamma 0.5-2", 2.0), ("weights x4, gamma 0.5-2", 4.0)])
 def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, capsys):
-    """The default arithmetic's distance from the 1e-4 contract at the bench's sequence length, 12+12 layers, in
-    three weight regimes, reported element-wise (|d| / max(|ref|, 1e-3 rms): 99.9th percentile and max) beside the
-    max-norm figure the other tests assert on.  The x4 regime (attention logits x16: saturated softmax rows) is
-    ill-conditioned for ANY fp32 implementation -- the exact-fp32 MFMA path itself lands ~1e-3 from the CPU oracle
-    there (measured on MI355X: 9.7e-4), the split modes no closer -- so it is reported, not asserted: it says how far
-    the 1e-4 contract can be trusted, not which arithmetic is better."""
+    """Every arithmetic's distance from the 1e-4 contract at the bench's sequence length, 12+12 layers, in three
+    weight regimes, reported element-wise (|d| / max(|ref|, 1e-3 rms): 99.9th percentile and max) beside the max-norm
+    figure the other tests assert on.  Asserted at random init.  The scaled regimes (attention logits x4 / x16:
+    saturating softmax rows) are ill-conditioned for ANY fp32 implementation -- measured on MI355X, max-norm vs the
+    CPU oracle: exact-fp32 MFMA 1.6e-4 (x2) / 9.7e-4 (x4), bf16x6 8e-5 / 0.47, bf16x3 8e-4 / 0.47 -- so they are
+    reported, not asserted: they say how far the 1e-4 contract itself can be trusted and that every split arithmetic
+    tracks the fp32 rounding error of the model by a constant factor (bf16x3 ~8x, f16x3 and bf16x6 ~1x)."""
     from test_structure_gpu import build
     L, B = 256, 2
     model, sd = build(pkg, FULL_STRUCT, L, seed=71)
@@ -385,7 +386,7 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
                         pk["receptor_angles"], pk["receptor_attn_mask"])
     m = pk["ligand_attn_mask"].bool()
     rows = {}
-    for mode in ("bf16x3", "bf16x6", "f32"):
+    for mode in ("bf16x3", "f16x3", "bf16x6", "f32"):
         with pkg.ops.arithmetic(mode, respect_env=False), torch.no_grad():
             got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
                         d["receptor_attn_mask"]).cpu()
@@ -394,8 +395,8 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
     with capsys.disabled():
         for mode, (mx, p999, emax) in rows.items():
             print(f"\n[margin, {regime}, L=256 12+12, {mode}] max-norm {mx:.2e} | element-wise p99.9 {p999:.2e} max {emax:.2e}")
-    if scale <= 2.0:
-        assert rows["bf16x3"][0] < TOL and rows["bf16x6"][0] < TOL and rows["f32"][0] < TOL
+    if scale == 1.0:
+        assert rows["bf16x3"][0] < TOL and rows["bf16x6"][0] < TOL and rows["f32"][0] < TOL and rows["f16x3"][0] < TOL
         # element-wise, floor 1e-3 rms: outputs 1000x below the rms carry the same ABSOLUTE error as the large ones, so
         # the percentile sits ~10-20x above the max-norm figure in every arithmetic (fp32 itself: 4e-5 vs 3e-6)
         assert rows["bf16x3"][1] < 2e-3 and rows["bf16x6"][1] < 2e-4

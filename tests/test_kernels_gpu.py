@@ -22,7 +22,7 @@ def g(seed):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 32), (130, 256, 64), (257, 768, 768), (1000, 1024, 3072),
                                    (64, 4608, 768), (4096, 2304, 768)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-@pytest.mark.parametrize("mode,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 3e-5)])
+@pytest.mark.parametrize("mode,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 3e-5), ("f16x3", 5e-6)])
 def test_gemm_bias_act(pkg, hip, M, N, K, act, mode, tol):
     """All three arithmetic modes against an fp64 statement: exact fp32 MFMA, and fp32 operands
     split into 3 / 2 bf16 terms on the bf16 matrix cores (fp32 accumulate)."""
@@ -50,7 +50,7 @@ def test_gemm_large_m_kernels(pkg, hip, M, N, K, act):
     ref = F.linear(a.double(), w.double(), b.double())
     ref = {0: lambda x: x, 1: F.gelu, 2: F.silu}[act](ref).float()
     a_dev = wide.to(DEV)[:, 32:32 + K]
-    for mode, tol in (("bf16x3", 3e-5), ("bf16x6", 5e-6)):
+    for mode, tol in (("bf16x3", 3e-5), ("bf16x6", 5e-6), ("f16x3", 5e-6)):
         got = pkg.ops.gemm(a_dev, w.to(DEV), b.to(DEV), act, mode=mode)
         assert rel_err(got, ref) < tol, mode
         # every row and column block is right, not only the global max-norm
@@ -98,7 +98,7 @@ def ref_attention(q, k, v, mask, E, P):
 @pytest.mark.parametrize("B,nh,L,P", [(2, 4, 16, 16), (1, 12, 64, 64), (3, 2, 50, 64), (2, 12, 128, 128),
                                       (1, 3, 256, 256), (2, 1, 33, 40)])
 @pytest.mark.parametrize("relkey", [True, False])
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4), ("f16x3", 1e-5)])
 def test_attention_self(pkg, hip, B, nh, L, P, relkey, mode, tol):
     H = nh * 64
     qkv = torch.randn(B * L, 3 * H, generator=g(L))
@@ -129,7 +129,7 @@ def test_attention_cross_rectangular_and_nomask(pkg, hip):
     dkv = kv.to(DEV)
     sp = lambda x, L: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
     ref = ref_attention(sp(qb, Lq), sp(kv[:, :H], Lk), sp(kv[:, H:], Lk), None, None, 0)
-    for mode, tol in (("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4)):
+    for mode, tol in (("f32", 1e-5), ("bf16x6", 1e-5), ("bf16x3", 1e-4), ("f16x3", 1e-5)):
         got = pkg.ops.attention(qb.to(DEV), dkv[:, :H], dkv[:, H:], B, nh, Lq, Lk, mode=mode)
         assert rel_err(got, ref.permute(0, 2, 1, 3).reshape(B * Lq, H).float()) < tol, mode
 
@@ -149,7 +149,7 @@ def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):
     assert rel_err(a, torch.softmax(s, -1) @ v) < 5e-3
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6", "f16x3"])
 def test_attention_padded_tile_skipping_is_bit_exact(pkg, hip, mode):
     """Stopping the key sweep after the last valid key's tile must not change a single bit
     (trailing padding tiles contribute exp(-10000 - m) == 0), incl. masks with holes and an
@@ -345,8 +345,9 @@ def test_distance_table_planes_cache_follows_weight_updates(pkg, hip):
     assert torch.equal(out2, fresh) and not torch.equal(out2, out1)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("relkey", [True, False])
-def test_attention_deferred_rescale_branch_is_forced_and_exact(pkg, hip, relkey):
+def test_attention_deferred_rescale_branch_is_forced_and_exact(pkg, hip, relkey, mode):
     """The cooperative kernel only raises its running softmax maximum when a key tile exceeds it by more than 2^tau
     (tau = 8): bounded random data never takes that branch after the first tile, so force it -- spiked keys in late
     tiles (one query jumps at tile 6, another at tile 3 AND again at tile 7, a third by LESS than tau so that it keeps
@@ -375,7 +376,7 @@ def test_attention_deferred_rescale_branch_is_forced_and_exact(pkg, hip, relkey)
         try:
             outs[tau] = pkg.ops.attention(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),
                                           dist_emb=None if E is None else E.to(DEV), max_pos=P, want_lse=True,
-                                          mode="bf16x3")
+                                          mode=mode)
         finally:
             hip.e3d_attn_rescale_tau(prev)
     split = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
@@ -392,3 +393,35 @@ def test_attention_deferred_rescale_branch_is_forced_and_exact(pkg, hip, relkey)
         assert rel_err(lse, lse_ref) < 1e-4, tau
         assert (got[5].cpu() - ref[5]).abs().max() < 1e-4 * ref.abs().max()      # the spiked query itself
     assert rel_err(outs[8.0][0], outs[0.0][0]) < 1e-5 and rel_err(outs[8.0][1], outs[0.0][1]) < 1e-5   # measured 4e-6
+
+
+def test_f16x3_range_contract(pkg, hip):
+    """f16x3 = two fp16 terms per operand (include/e3d_hip.h, E3D_TERMS_F16X3): fp32-grade for operands inside the
+    fp16 range.  The contract at its edges, against fp64: (1) elements far below 2^-14 keep an ABSOLUTE error of
+    2^-25 each (a relative one would need the exponent range fp16 lacks) -- norm-wise still fp32 grade when the
+    operand's large elements are O(1); (2) a uniformly tiny operand (every |w| ~ 1e-6) degrades gracefully to that
+    absolute floor; (3) values beyond 65504 turn the affected outputs into inf/NaN -- loud, never silently wrong;
+    (4) bf16x6 has none of these limits."""
+    M, N, K = 512, 256, 768
+    a = torch.randn(M, K, generator=g(1))
+    w = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    ref = a.double() @ w.double().t()
+    assert rel_err(pkg.ops.gemm(a.to(DEV), w.to(DEV), None, mode="f16x3"), ref.float()) < 2e-6
+    # (1) wide dynamic range inside one operand: columns spanning 1e-6 .. 1e2
+    scale = torch.logspace(-6, 2, K)
+    a2, w2 = a * scale[None, :], w / scale[None, :].clamp_min(1e-3)
+    ref2 = a2.double() @ w2.double().t()
+    err2 = rel_err(pkg.ops.gemm(a2.to(DEV), w2.to(DEV), None, mode="f16x3"), ref2.float())
+    assert err2 < 2e-5, err2
+    assert rel_err(pkg.ops.gemm(a2.to(DEV), w2.to(DEV), None, mode="bf16x6"), ref2.float()) < 5e-6
+    # (2) a uniformly tiny weight matrix: the absolute floor 2^-25 per element shows (relative error ~ 2^-25 / 1e-6)
+    w3 = w * 1e-4
+    ref3 = a.double() @ w3.double().t()
+    err3 = rel_err(pkg.ops.gemm(a.to(DEV), w3.to(DEV), None, mode="f16x3"), ref3.float())
+    assert err3 < 2e-2 and rel_err(pkg.ops.gemm(a.to(DEV), w3.to(DEV), None, mode="bf16x6"), ref3.float()) < 5e-6
+    # (3) out-of-range operands are loud
+    a4 = a.clone()
+    a4[3, 17] = 1.0e5
+    got4 = pkg.ops.gemm(a4.to(DEV), w.to(DEV), None, mode="f16x3")
+    assert not torch.isfinite(got4[3]).all() and torch.isfinite(got4[4:]).all()
+    assert torch.isfinite(pkg.ops.gemm(a4.to(DEV), w.to(DEV), None, mode="bf16x6")).all()

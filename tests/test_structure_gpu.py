@@ -113,7 +113,7 @@ def test_gemm_arithmetic_modes_end_to_end(pkg, hip, capsys):
                         pk["receptor_angles"], pk["receptor_attn_mask"])
     d = to_dev(pk)
     errs = {}
-    for mode, bound in (("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", TOL / 2)):
+    for mode, bound in (("f32", 2e-5), ("bf16x6", 2e-5), ("bf16x3", TOL / 2), ("f16x3", 2e-5)):
         prev, prev_a = pkg.ops.set_gemm_mode(mode), pkg.ops.set_attn_mode(mode)
         try:
             got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
