@@ -185,8 +185,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pockets per GPU")
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default=os.environ.get("E3D_GEMM_MODE", "bf16x3"),
-                    choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--gemm-mode", default=os.environ.get("E3D_GEMM_MODE", "f16x3"),
+                    choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="GEMM arithmetic of the headline value (see DESIGN.md section 3)")
     ap.add_argument("--only-default-mode", action="store_true", help="skip timing the other GEMM modes")
     ap.add_argument("--headline-only", action="store_true",
@@ -365,7 +365,7 @@ def main():
             traffic = tdict.get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
             gemm_traffic = tdict.get(f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch")
         a_tf = attn_flops(B, L) / (attn_ms * 1e-3) / 1e12
-        gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.gemm_mode]
+        gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6, "f16x3": 2500.0 / 3}[args.gemm_mode]
         a_gb = attn_bytes(B, L) / (attn_ms * 1e-3) / 1e9
         out = {
             "metric": "denoising-steps/sec (batched pocket graphs)",
@@ -378,7 +378,10 @@ def main():
             "gemm_mode": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                           "bf16x3": "fp32 operands split into 2 bf16 terms, 3 cross products on the bf16 MFMA, fp32 accumulate",
                           "bf16x6": "fp32 operands split into 3 bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate "
-                                    "(fp32-grade)"}[args.gemm_mode],
+                                    "(fp32-grade)",
+                          "f16x3": "fp32 operands split into 2 fp16 terms (11 + 11 bits), 3 cross products on the fp16 MFMA, fp32 "
+                                   "accumulate (fp32-grade: 4.9e-6 end to end at L=256 vs 3.2e-6 for the exact fp32 MFMA path; "
+                                   "operands must lie inside the fp16 range)"}[args.gemm_mode],
             "value_by_gemm_mode": {m: B * world / by_mode[m] for m in modes},
             "config": {"workload": f"structure_model sampling step, {B} x {L}-residue pockets per GPU, "
                                    "12+12 layers x 768, T=1000 schedule, encoder recomputed every step (as the reference)",
@@ -397,13 +400,13 @@ def main():
             # peak) and HBM time (algorithmic bytes / 8 TB/s) is larger; frac = that time / measured time
             "roofline_attention": (lambda t_mfma, t_hbm: {
                 "kernel": ("attn_fwd_kernel<relkey> (e3d_relkey_attn_fwd)" if args.gemm_mode == "f32" else
-                           f"attn_coop_kernel<8 waves, relkey> for bf16x3, attn_fwd_split_kernel / attn_fwd_kernel otherwise (e3d_relkey_attn_fwd_split, {args.gemm_mode})"),
+                           f"attn_coop_kernel<8 waves, relkey> for bf16x3 / f16x3, attn_fwd_split_kernel / attn_fwd_kernel otherwise (e3d_relkey_attn_fwd_split, {args.gemm_mode})"),
                 "bound": "hbm" if t_hbm > t_mfma else "mfma",
                 "achieved": a_gb if t_hbm > t_mfma else a_tf,
                 "peak": PEAK_HBM_GBPS if t_hbm > t_mfma else gemm_peak,
                 "unit": "GB/s" if t_hbm > t_mfma else "TFLOP/s",
                 "frac": max(t_hbm, t_mfma) / attn_ms, "traffic": traffic,
-                "peak_note": "MFMA peak: fp32 157.3 TFLOP/s for f32; bf16 dense 2500 / terms for the split modes",
+                "peak_note": "MFMA peak: fp32 157.3 TFLOP/s for f32; bf16 / fp16 dense 2500 / cross products for the split modes",
                 "avg_launch_ms": attn_ms, "launches_per_step": n_attn, "dense_key_sweep": True,
                 "algorithmic_TFLOPs": a_tf, "mfma_frac": a_tf / gemm_peak,
                 "hbm_algorithmic_GBps": a_gb, "hbm_frac": a_gb / PEAK_HBM_GBPS})(
@@ -411,7 +414,7 @@ def main():
             # the dominant kernel (~56 % of the step's kernel time): all its launches of one step.  flops per launch =
             # 2MNK, bytes per launch = 4(MK + NK + MN + N), averaged over those launches; peak = the
             # dense bf16 MFMA rate / cross products per fp32 product
-            "roofline": {"kernel": ("gemm_split256p_kernel<ACT_NONE> (e3d_gemm_bias_act_f32_split), " if args.gemm_mode == "bf16x3"
+            "roofline": {"kernel": ("gemm_split256p_kernel<ACT_NONE> (e3d_gemm_bias_act_f32_split), " if args.gemm_mode in ("bf16x3", "f16x3")
                                     else f"large-M GEMM kernel of mode {args.gemm_mode}, ") +
                                    f"all {len(dom)} launches of one step (M={B * L}; N, K in gemm_shapes)",
                          "bound": "mfma", "achieved": dom_flops / (dom_ms * 1e-3) / 1e12, "peak": gemm_peak, "unit": "TFLOP/s",

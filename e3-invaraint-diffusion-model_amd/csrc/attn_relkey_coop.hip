@@ -278,8 +278,14 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const f32x4 lo4 = qraw[2 * kb], hi4 = qraw[2 * kb + 1];
-        const float x[8] = {lo4[0] * Q_SCALE, lo4[1] * Q_SCALE, lo4[2] * Q_SCALE, lo4[3] * Q_SCALE,
-                            hi4[0] * Q_SCALE, hi4[1] * Q_SCALE, hi4[2] * Q_SCALE, hi4[3] * Q_SCALE};
+        float x[8] = {lo4[0] * Q_SCALE, lo4[1] * Q_SCALE, lo4[2] * Q_SCALE, lo4[3] * Q_SCALE,
+                      hi4[0] * Q_SCALE, hi4[1] * Q_SCALE, hi4[2] * Q_SCALE, hi4[3] * Q_SCALE};
+        // Pin the rounded fp32 products before the split.  With fp16 terms hipcc may otherwise form the hi term by a
+        // mixed-precision fused multiply-convert (ONE rounding of the exact product) but the residual from the
+        // fp32-rounded product (TWO roundings): at a double-rounding tie the two disagree by one fp16 ulp and the
+        // lo term no longer complements the hi term (found as a 2^-10 error on 1 of 49152 query elements).
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(x[j]));
         split8x2(x, qf[kb][0], qf[kb][1]);
     }
     if (RELKEY) {

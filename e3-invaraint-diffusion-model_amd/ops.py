@@ -121,7 +121,7 @@ except ImportError:      # very old torch: training.fit() bumps the generation a
 # inside the fp16 range (|x| < 65504 -- larger values give inf/NaN, loudly; include/e3d_hip.h E3D_TERMS_F16X3);
 # forward GEMMs and the cooperative attention kernel, every other path of that mode runs bf16x6 / fp32 kernels.
 GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6, "f16x3": 19}
-GEMM_MODE = os.environ.get("E3D_GEMM_MODE", "bf16x3")
+GEMM_MODE = os.environ.get("E3D_GEMM_MODE", "f16x3")   # inference default: fp32 grade at bf16x3 speed
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"E3D_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {GEMM_MODE!r}")
 

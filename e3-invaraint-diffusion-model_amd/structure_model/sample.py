@@ -35,9 +35,9 @@ GPU_ID = 0
 STEP = 1  # stride over timesteps; >1 trades quality for speed (reference sample.py:16)
 # Arithmetic of this entry point.  The reference's structure_model/sample.py never calls
 # torch.set_float32_matmul_precision (only the train scripts and the sequence sampler set "medium"), i.e. it
-# samples at full fp32: ``sample()`` therefore runs the fp32-grade bf16x6 kernels unless E3D_GEMM_MODE says
-# otherwise.  (bench.py times bf16x3 -- inside the 1e-4 contract -- and reports every mode on its line.)
-ARITHMETIC = "bf16x6"
+# samples at full fp32: ``sample()`` runs the fp32-grade f16x3 kernels (two fp16 terms per operand, see ops.py; 4.9e-6
+# from the CPU oracle end to end vs 3.2e-6 for the exact fp32 MFMA path) unless E3D_GEMM_MODE says otherwise.
+ARITHMETIC = "f16x3"
 
 CONFIG = {
     "pocket_ext": 0,

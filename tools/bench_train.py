@@ -66,6 +66,8 @@ def main():
         optim.step()
         return loss
 
+    mode = pkg.ops.arithmetic(pkg.training.TRAIN_ARITHMETIC)   # bf16x3 unless E3D_GEMM_MODE says otherwise
+    mode.__enter__()
     for _ in range(2):
         step()
     torch.cuda.synchronize()
