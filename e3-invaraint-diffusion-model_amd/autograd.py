@@ -88,21 +88,6 @@ def _transposed_weight(weight):
     return wt
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """One auxiliary stream per device for the weight-gradient GEMMs (E3D_BWD_STREAMS=0 disables the overlap)."""
-    import os
-    if os.environ.get("E3D_BWD_STREAMS", "1") != "1" or torch.cuda.is_current_stream_capturing():
-        return None
-    key = torch.device(device).index
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b); training keeps the pre-activation z (the inference path fuses act into
     the GEMM epilogue instead)."""
@@ -123,38 +108,15 @@ class _Linear(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         dx = dw = db = None
-        want_dw = ctx.needs_input_grad[1]
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        # The weight / bias gradients do not feed the rest of the backward chain: at training sizes (M = 4096 ..
-        # 8192 rows: 48-192 workgroups per GEMM on 256 CUs, each latency-bound at one workgroup per CU) they run on a
-        # SIDE stream beside the input-gradient GEMM, so the CUs hold two workgroups of two independent kernels.  The
-        # main stream waits for the side stream before this function returns (autograd consumes dw / db on it).
-        side = _side_stream(dz.device) if (want_dw or want_db) and ctx.needs_input_grad[0] and M >= 1024 else None
-        if side is not None:
-            main = torch.cuda.current_stream(dz.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if want_dw:
-                    dw = gemm_general(dz, True, x, True, N, K, M)            # dz^T [N,M] . x [M,K]
-                if want_db:
-                    db = colsum(dz)
-            for t in (dw, db):                 # allocated on the side stream, consumed on the main one
-                if t is not None:
-                    t.record_stream(main)
-            dz.record_stream(side)             # allocated on the main stream, read on the side one
-            x.record_stream(side)
         if ctx.needs_input_grad[0]:
             if K % 128 == 0 and N % 32 == 0 and M >= 1024:
                 dx = ops.gemm(dz, _transposed_weight(weight), None)      # dz [M,N] . (W^T [K,N])^T
             else:
                 dx = gemm_general(dz, False, weight, True, M, K, N)      # dz [M,N] . W[N,K]
-        if side is not None:
-            torch.cuda.current_stream(dz.device).wait_stream(side)
-        else:
-            if want_dw:
-                dw = gemm_general(dz, True, x, True, N, K, M)
-            if want_db:
-                db = colsum(dz)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_general(dz, True, x, True, N, K, M)                # dz^T [N,M] . x [M,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dz)
         return dx, dw, db, None
 
 
