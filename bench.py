@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="pockets per GPU")
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the extra training-step timings")
     ap.add_argument("--gemm-mode", default=os.environ.get("E3D_GEMM_MODE", "f16x3"),
                     choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="GEMM arithmetic of the headline value (see DESIGN.md section 3)")
@@ -432,6 +433,16 @@ def main():
                               "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes",
                               "ms_per_step": gemm_ms},
         }
+        if world == 1 and not args.headline_only and not args.no_train_leg:
+            # extra keys (never the headline): one training step of BASELINE configs 2 and 4, one GPU's share
+            del model
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_train
+            out["train"] = {"structure_B32_L128": bench_train.run("structure", steps=5),
+                            "sequence_B64_L128": bench_train.run("sequence", steps=5),
+                            "note": "forward + loss + backward + grad-norm clip + fused AdamW, 12+12 / 6 layers x 768, "
+                                    "synthetic batches, dropout 0 (the reference's 0.1 costs +0.7 ms)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, seed=0)
         print(json.dumps(out), flush=True)

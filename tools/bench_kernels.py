@@ -82,6 +82,25 @@ def attn_pmc():
     torch.cuda.synchronize()
 
 
+def attn_shapes():
+    """The rel-key attention kernel at the three sequence lengths of BASELINE.json (same token count) for a
+    rocprofv3 --kernel-trace --stats run: L = 64 (per-wave kernel), 128 (4-wave cooperative), 256 (8-wave
+    cooperative), default arithmetic, 20 launches each; prints the HIP-event average next to the algorithmic rates."""
+    nh, H = 12, 768
+    for B, L in ((1024, 64), (512, 128), (256, 256)):
+        qkv = torch.randn(B * L, 3 * H, device=DEV)
+        E = torch.randn(2 * L - 1, 64, device=DEV)
+        mask = torch.ones(B, L, device=DEV)
+        with torch.no_grad():
+            fn = lambda: ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,  # noqa: E731
+                                       dist_emb=E, max_pos=L)
+            ms = time_ms(fn, iters=4, rounds=5)
+        fl = 6.0 * L * L * H * B
+        by = (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B
+        print(f"attn relkey {ops.ATTN_MODE} B={B} L={L}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TF  {by / ms / 1e6:.0f} GB/s algorithmic "
+              f"= {by / ms / 1e6 / 8000:.3f} of 8 TB/s", flush=True)
+
+
 def gemm_pmc():
     """Few launches of the dominant GEMM shape (65536 x 2304 x 768: the packed QKV projection, default mode)
     for a rocprofv3 --pmc pass; another N as the second argument."""
@@ -96,4 +115,4 @@ def gemm_pmc():
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-    {"gemm": bench_gemm, "attn": bench_attn, "attn_pmc": attn_pmc, "gemm_pmc": gemm_pmc}[what]()
+    {"gemm": bench_gemm, "attn": bench_attn, "attn_pmc": attn_pmc, "gemm_pmc": gemm_pmc, "attn_shapes": attn_shapes}[what]()

@@ -23,22 +23,17 @@ from e3diff_amd.bert import BertConfig  # noqa: E402
 DEV = "cuda:0"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("model", nargs="?", default="structure", choices=["structure", "sequence"])
-    ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--seq-len", type=int, default=128)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
-    args = ap.parse_args()
-    L = args.seq_len
-    layers = 12 if args.model == "structure" else 6
-    B = args.batch or (32 if args.model == "structure" else 64)
+def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2):
+    """One GPU's training step of BASELINE config 2 (structure, B=32) / config 4 (sequence, B=64): forward + loss +
+    backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict."""
+    L = seq_len
+    layers = 12 if model_name == "structure" else 6
+    B = batch or (32 if model_name == "structure" else 64)
     c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=layers,
-             max_position_embeddings=L, hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
+             max_position_embeddings=L, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
     enc, dec = BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True)
     torch.manual_seed(0)
-    if args.model == "structure":
+    if model_name == "structure":
         from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as M
         from e3diff_amd.structure_model.dataset import noise_batch_on_device
         from e3diff_amd.structure_model.utils import CosineTables
@@ -55,31 +50,44 @@ def main():
     pk = {k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=0, with_ligand_seq=True).items() if torch.is_tensor(v)}
 
     def step():
-        if args.model == "structure":
-            batch = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab))
+        if model_name == "structure":
+            batch_ = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab))
         else:
-            batch = pk
-        loss = model.training_step(batch)
+            batch_ = pk
+        loss = model.training_step(batch_)
         optim.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         optim.step()
         return loss
 
-    mode = pkg.ops.arithmetic(pkg.training.TRAIN_ARITHMETIC)   # bf16x3 unless E3D_GEMM_MODE says otherwise
-    mode.__enter__()
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    nparam = sum(p.numel() for p in params)
-    print(f"{args.model} training step: B={B} L={L} layers={layers} params={nparam / 1e6:.1f}M gemm_mode={pkg.ops.GEMM_MODE} dropout={args.dropout}: "
-          f"{dt * 1e3:.1f} ms/step = {B / dt:.1f} samples/s (loss {float(loss.detach()):.4f}, peak mem "
-          f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB)", flush=True)
+    with pkg.ops.arithmetic(pkg.training.TRAIN_ARITHMETIC):   # bf16x3 unless E3D_GEMM_MODE says otherwise
+        mode = pkg.ops.GEMM_MODE
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    return {"model": model_name, "batch": B, "seq_len": L, "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
+            "arithmetic": mode, "dropout": dropout, "ms_per_step": dt * 1e3, "samples_per_s": B / dt,
+            "loss": float(loss.detach()), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", nargs="?", default="structure", choices=["structure", "sequence"])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
+    args = ap.parse_args()
+    r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout)
+    print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} layers={r['layers']} params={r['params_M']:.1f}M "
+          f"gemm_mode={r['arithmetic']} dropout={r['dropout']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
+          f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB)", flush=True)
 
 
 if __name__ == "__main__":

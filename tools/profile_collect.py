@@ -35,9 +35,10 @@ def dump(rows, name):
         w.writerows(rows)
 
 
-GEMM = "gemm_split256p_kernel<0>"
-af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", "attn_coop_kernel<8, true>"), \
-    counter_rows(f"{O}/pmc_write/a_counter_collection.csv", "attn_coop_kernel<8, true>")
+GEMM = "gemm_split256p_kernel<0"     # <ACT_NONE, element type>: every instantiation of the plain-epilogue form
+ATTN = "attn_coop_kernel<8, true"
+af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", ATTN), \
+    counter_rows(f"{O}/pmc_write/a_counter_collection.csv", ATTN)
 gf, gw = counter_rows(f"{O}/pmc_gfetch/g_counter_collection.csv", GEMM), counter_rows(f"{O}/pmc_gwrite/g_counter_collection.csv", GEMM)
 (afm, _), (awm, _), (gfm, ng), (gwm, _) = mean(af), mean(aw), mean(gf), mean(gw)
 traffic = {
@@ -46,7 +47,7 @@ traffic = {
     "_detail": {
         "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes: FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes "
                    "(no trace domains); x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)",
-        "attn": {"kernel": "attn_coop_kernel<8, true>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
+        "attn": {"kernel": "attn_coop_kernel<8 waves, rel-key, default arithmetic>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
                  "WRITE_SIZE_KiB_avg": awm, "algorithmic_bytes": (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B},
         "gemm": {"kernel": f"{GEMM}: every launch of one bench.py --headline-only step ({ng} dispatches incl. the untimed "
                            "trace pass)", "FETCH_SIZE_KiB_raw_avg": gfm, "WRITE_SIZE_KiB_avg": gwm},
@@ -59,6 +60,14 @@ dump(aw, f"{tag}_attn_coop_B256_L256_pmc_write.csv")
 dump(gf, f"{tag}_gemm_act0_bench_step_pmc_fetch.csv")
 dump(gw, f"{tag}_gemm_act0_bench_step_pmc_write.csv")
 shutil.copy(f"{O}/stats/bench_kernel_stats.csv", os.path.join(P, f"{tag}_bench_B256_L256_kernel_stats.csv"))
+for sub, name in (("stats_attn/attn_kernel_stats.csv", "attn_relkey_L64_L128_L256_kernel_stats.csv"),
+                  ("stats_train_structure/t_kernel_stats.csv", "train_structure_B32_L128_kernel_stats.csv"),
+                  ("stats_train_sequence/t_kernel_stats.csv", "train_sequence_B64_L128_kernel_stats.csv")):
+    if os.path.exists(f"{O}/{sub}"):
+        shutil.copy(f"{O}/{sub}", os.path.join(P, f"{tag}_{name}"))
+for log in ("attn_shapes.log", "train_structure.log", "train_sequence.log"):
+    if os.path.exists(f"{O}/{log}"):
+        shutil.copy(f"{O}/{log}", os.path.join(P, f"{tag}_{log}"))
 line = [ln for ln in open(f"{O}/bench_under_rocprof.log") if ln.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench_line_under_rocprof.json"), "w").write(line)
 d = json.loads(line)

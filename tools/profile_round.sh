@@ -14,3 +14,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o a -- python3 $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gfetch -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gwrite -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gwrite.log 2>&1
 find $O -name "*.csv" | head -20
+# the rel-key attention kernel at L = 64 / 128 / 256 (rocprofv3 evidence instead of HIP events only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_attn -o attn -- python3 $R/tools/bench_kernels.py attn_shapes > $O/attn_shapes.log 2>&1
+# training steps (BASELINE configs 2 and 4, one GPU's share)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_structure -o t -- python3 $R/tools/bench_train.py structure --steps 5 > $O/train_structure.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_sequence -o t -- python3 $R/tools/bench_train.py sequence --steps 5 > $O/train_sequence.log 2>&1
+find $O -name "*stats.csv" | head -20
