@@ -16,6 +16,20 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// element type of the split terms: __bf16 (bf16x3 / bf16x6) or _Float16 (f16x3, NS = 2 only; include/e3d_hip.h)
+template <typename E> struct AV;
+template <> struct AV<__bf16> { typedef bf16x8 x8; };
+template <> struct AV<_Float16> { typedef f16x8 x8; };
+template <typename X> struct Elem;
+template <> struct Elem<bf16x8> { typedef __bf16 type; };
+template <> struct Elem<f16x8> { typedef _Float16 type; };
+__device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 constexpr int D = 64;
 constexpr int RING_LD = 34;
@@ -24,8 +38,9 @@ constexpr int STG_LD = 68;             // staging rows: 64 floats + 16 B pad (co
 constexpr int STG_F = 32 * STG_LD;
 constexpr int WAVE_LDS_F = RING_F + STG_F + 32;  // + per-tile key bias row
 
-template <int NS>
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&parts)[NS]) {
+template <int NS, typename X8>
+__device__ __forceinline__ void split8(const float (&x)[8], X8 (&parts)[NS]) {
+    typedef typename Elem<X8>::type E;
     float r[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = x[j];
@@ -33,15 +48,15 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 (&parts)[NS])
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const __bf16 p = (__bf16)r[j];
+            const E p = (E)r[j];
             parts[s][j] = p;
             r[j] -= (float)p;
         }
 }
 
 // one row's 64 head-dim values -> 4 k-blocks x NS parts (lane takes floats 16kb + 8h .. +7)
-template <int NS>
-__device__ __forceinline__ void load_row_split(bf16x8 (&f)[4][NS], const float* row_ptr, int half) {
+template <int NS, typename X8>
+__device__ __forceinline__ void load_row_split(X8 (&f)[4][NS], const float* row_ptr, int half) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(row_ptr + 16 * kb + 8 * half);
@@ -73,8 +88,8 @@ __device__ __forceinline__ void tile_load(TileRegs& t, const float* base, int rs
     }
 }
 
-template <int NS>
-__device__ __forceinline__ void tile_to_frags(bf16x8 (&f)[4][NS], const TileRegs& t, float* stg, int lane) {
+template <int NS, typename X8>
+__device__ __forceinline__ void tile_to_frags(X8 (&f)[4][NS], const TileRegs& t, float* stg, int lane) {
     __builtin_amdgcn_wave_barrier();  // earlier readers of the staging buffer are done (in-order LDS)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -115,22 +130,22 @@ __device__ __forceinline__ void v_load(VRegs& t, const float* vb, int v_rs, int 
 }
 
 // acc += sum over the significant cross terms of a (A operand parts) x b (B operand parts)
-template <int NS>
-__device__ __forceinline__ f32x16 mfma_terms(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x16 acc) {
+template <int NS, typename X8>
+__device__ __forceinline__ f32x16 mfma_terms(const X8 (&a)[NS], const X8 (&b)[NS], f32x16 acc) {
     if (NS == 3) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[NS - 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NS - 1], b[0], acc, 0, 0, 0);
+        acc = mma16(a[1], b[1], acc);
+        acc = mma16(a[0], b[NS - 1], acc);
+        acc = mma16(a[NS - 1], b[0], acc);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    acc = mma16(a[0], b[1], acc);
+    acc = mma16(a[1], b[0], acc);
+    acc = mma16(a[0], b[0], acc);
     return acc;
 }
 
 // tile[i][j] = X_i . Y_j (i on accumulator rows, j on lanes)
-template <int NS>
-__device__ __forceinline__ f32x16 dot_tile(const bf16x8 (&x)[4][NS], const bf16x8 (&y)[4][NS]) {
+template <int NS, typename X8>
+__device__ __forceinline__ f32x16 dot_tile(const X8 (&x)[4][NS], const X8 (&y)[4][NS]) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -139,12 +154,13 @@ __device__ __forceinline__ f32x16 dot_tile(const bf16x8 (&x)[4][NS], const bf16x
     return acc;
 }
 
-template <int NS, bool RELKEY, bool DROP>
+template <int NS, bool RELKEY, bool DROP, typename E>
 __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq,
     int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dDrop drop) {
+    typedef typename AV<E>::x8 bf16x8;   // (name kept from the bf16 form: 8 split terms of type E)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qi = lane & 31, half = lane >> 5;
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
 
 int g_skip_padded = 1;
 
-template <int NS, bool DROP = false>
+template <int NS, bool DROP = false, typename E = __bf16>
 int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
            int64_t v_bs, int64_t v_rs, const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
            int B, int nh, int Lq, int Lk, hipStream_t s, E3dDrop drop = E3dDrop{0, 0, 1.f}) {
@@ -314,10 +330,10 @@ int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k
     const int n_blocks = (n_units + wpb - 1) / wpb;
     const size_t lds = (size_t)wpb * WAVE_LDS_F * sizeof(float);
     if (dist_emb)
-        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true, DROP>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
+        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true, DROP, E>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
                            k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
     else
-        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false, DROP>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
+        hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false, DROP, E>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
                            k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
     return e3d_launch_status("e3d_relkey_attn_fwd_split");
 }
@@ -376,7 +392,9 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
                                     Lq, Lk, g_skip_padded, e_scratch, e_scratch_ready, f16, s);
-    // f16x3 exists in the cooperative kernel only: other shapes run the fp32-grade bf16x6 per-wave kernel
+    if (f16)
+        return launch<2, false, _Float16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
+                                          Lq, Lk, s);
     if (terms == 3)
         return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
     return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);

@@ -140,8 +140,11 @@ struct Stager {
 
 // WM = waves along M: 4 -> 256x128 tile, 512 threads; 2 -> 128x128 tile, 256 threads (used for grids of a few
 // tiles only: it halves the padded rows of an M = 64 problem; at M = 4096 it measured 25 % slower than WM = 4).
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
-__global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
+// WN = waves along N (64 columns each).  WN = 1 (128 x 64 tiles of two waves, three workgroups per CU, twice the grid)
+// was measured for the medium-M launches of training and trimmed sampling and is not dispatched: 45 us against 31 us
+// for the 128 x 128 form at M = 4096, N = K = 768 (two waves per workgroup hide even less of the k-step chain).
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M,
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
                                                          int k_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NBUF = NS == 2 ? 2 : 1;
-    constexpr int BM = WM * 64, NT = WM * 128;
+    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
     constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
 
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_kernel(const float* __res
     const int row0 = tm * BM, col0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WN, wc = wid % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
     Stager<BM, A_KMAJ, NT> sa;
@@ -685,6 +688,7 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
     return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
 }
 
+int g_general_form = -1;   // E3D_GEMM_FORM, e3d_gemm_general_select: 0 = by shape
 int g_tile_pref = -1;  // E3D_GEMM_TILE (A/B runs): 0 = 256x128 (8 waves of 64x64) for every shape, 1 = 256x256 classic
                        // loop, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
 
@@ -701,7 +705,7 @@ int launch256(const float* A, int64_t lda, const float* W, const float* bias, fl
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s);
 
@@ -734,32 +738,43 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
             (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
             return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, s);
     }
-    // a handful of 256-row tiles (single-pocket sampling): 128-row tiles
-    static int wm_pref = -1;   // E3D_GEMM_WM = 2 / 4 forces a form (experiments)
-    if (wm_pref < 0) {
-        const char* e = getenv("E3D_GEMM_WM");
-        wm_pref = e ? atoi(e) : 0;
+    // general kernel, two tile forms: 1 = 256x128 (8 waves, one workgroup per CU: 96 KB of LDS), 2 = 128x128 (4 waves,
+    // two per CU).  Both are bound by the latency of a workgroup's own k-step chain at these sizes, so the choice is a
+    // matter of rounds (tools/lab/gemm_forms_ab.py, K = 768: a 128x128 workgroup alone on its CU takes ~29 us, ~45 us
+    // when it shares the CU; a 256x128 one ~37 us): E3D_GEMM_FORM / e3d_gemm_general_select force a form.
+    if (g_general_form < 0) {
+        const char* e = getenv("E3D_GEMM_FORM");
+        g_general_form = e ? atoi(e) : 0;
     }
-    const int tiles256 = ((M + 255) / 256) * ((N + BN - 1) / BN);
-    // (measured: a win only for very small grids -- single-pocket sampling; at M = 4096 the 256-row form is 25 % faster)
-    if (NS == 2 && (wm_pref == 2 || (wm_pref == 0 && tiles256 < 128 && !A_KMAJ && !B_KMAJ)))
-        return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
-    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    int form = g_general_form;
+    if (form != 1 && form != 2) {
+        const int64_t g256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), g128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+        const int64_t cus = e3d_cu_count();
+        if (NS != 2) form = g256 < 128 && !A_KMAJ && !B_KMAJ ? 2 : 1;       // 3-term kernels: as measured in round 1
+        else if (A_KMAJ && B_KMAJ) form = 1;                                // weight gradients (split-K over one resident round): +4 %
+        else if (g128 <= cus) form = 2;
+        else if (g256 <= cus) form = 1;
+        else form = 45 * ((g128 + 2 * cus - 1) / (2 * cus)) < 37 * ((g256 + cus - 1) / cus) ? 2 : 1;
+    }
+    if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s) {
-    constexpr int BM = WM * 64;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    constexpr int BM = WM * 64, BNt = WN * 64;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BNt - 1) / BNt;
     constexpr int NBUF = NS == 2 ? 2 : 1;
-    const size_t lds = (size_t)NBUF * NS * (BM + BN) * ROW_B;
+    const size_t lds = (size_t)NBUF * NS * (BM + BNt) * ROW_B;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, E>, lds);
-    // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count
+    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>, lds);
+    // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count; one round of
+    // resident workgroups (more slices only add atomics: measured in round 1)
     int splits = 1;
-    if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n < 32 * WM && K >= 1024) {
-        splits = 64 * WM / (tiles_m * tiles_n);
+    const int resident = e3d_cu_count() * (WM * WN >= 8 ? 1 : 2);   // workgroups the chip holds at once (LDS-limited)
+    if (A_KMAJ && B_KMAJ && ACT == E3D_ACT_NONE && tiles_m * tiles_n * 2 < resident && K >= 1024) {
+        splits = resident / (tiles_m * tiles_n);
         splits = splits > 16 ? 16 : splits;
         while (splits > 1 && K / splits < 256) --splits;
     }
@@ -775,8 +790,8 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
             return (int)e;
         }
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, E>), dim3(tiles_m * tiles_n, splits), dim3(WM * 128),
-                       lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>), dim3(tiles_m * tiles_n, splits),
+                       dim3(WM * WN * 64), lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
     return e3d_launch_status("e3d_gemm_f32_split");
 }
 
@@ -817,6 +832,16 @@ extern "C" int e3d_gemm_kernel_select(int pref) {
     }
     const int prev = g_tile_pref;
     if (pref >= 0) g_tile_pref = pref;
+    return prev;
+}
+
+extern "C" int e3d_gemm_general_select(int form) {
+    if (g_general_form < 0) {
+        const char* e = getenv("E3D_GEMM_FORM");
+        g_general_form = e ? atoi(e) : 0;
+    }
+    const int prev = g_general_form;
+    if (form >= 0) g_general_form = form;
     return prev;
 }
 

@@ -24,6 +24,7 @@ _SIGNATURES = {
                                           _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "e3d_attn_skip_padded_tiles": (c_int, [c_int]),
     "e3d_gemm_kernel_select": (c_int, [c_int]),
+    "e3d_gemm_general_select": (c_int, [c_int]),
     "e3d_attn_rescale_tau": (c_float, [c_float]),
     "e3d_residual_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, _P]),
     "e3d_adaln_gate_fwd": (c_int, [_P, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),

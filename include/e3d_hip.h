@@ -98,6 +98,10 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
  * staging, 1 = classic 256x256 loop, 0 = 256x128.  Results are identical in every form (same products, same
  * accumulation order).  pref < 0 only queries.  Returns the previous value. */
 int e3d_gemm_kernel_select(int pref);
+/* The same for the general kernel (every launch the persistent / 256x256 forms do not take: medium and small M, the
+ * training layouts): 0 = by shape (default), 1 = 256x128 tiles (8 waves), 2 = 128x128 (4 waves).  Identical results
+ * in every form (up to the order of the split-K atomics of the weight-gradient layout).  form < 0 only queries. */
+int e3d_gemm_general_select(int form);
 
 /* Diagnostic (tests/test_kernels_gpu.py): the cooperative bf16x3 attention kernel keeps its running softmax maximum
  * until a key tile exceeds it by more than 2^tau (default tau = 8, log2 units; results are mathematically

@@ -17,8 +17,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 B, L, H = 256, 256, 768
 
 
-def counter_rows(path, needle):
-    return [r for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"]]
+def counter_rows(path, needles):
+    """rows of the kernels whose name contains one of ``needles`` (rocprofv3 prints demangled or mangled names
+    depending on the run)"""
+    return [r for r in csv.DictReader(open(path)) if any(n in r["Kernel_Name"] for n in needles)]
 
 
 def mean(rows):
@@ -35,8 +37,8 @@ def dump(rows, name):
         w.writerows(rows)
 
 
-GEMM = "gemm_split256p_kernel<0"     # <ACT_NONE, element type>: every instantiation of the plain-epilogue form
-ATTN = "attn_coop_kernel<8, true"
+GEMM = ("gemm_split256p_kernel<0", "gemm_split256p_kernelILi0E")   # <ACT_NONE, element type>, demangled / mangled
+ATTN = ("attn_coop_kernel<8, true", "attn_coop_kernelILi8ELb1E")
 af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", ATTN), \
     counter_rows(f"{O}/pmc_write/a_counter_collection.csv", ATTN)
 gf, gw = counter_rows(f"{O}/pmc_gfetch/g_counter_collection.csv", GEMM), counter_rows(f"{O}/pmc_gwrite/g_counter_collection.csv", GEMM)
@@ -49,7 +51,7 @@ traffic = {
                    "(no trace domains); x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)",
         "attn": {"kernel": "attn_coop_kernel<8 waves, rel-key, default arithmetic>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
                  "WRITE_SIZE_KiB_avg": awm, "algorithmic_bytes": (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B},
-        "gemm": {"kernel": f"{GEMM}: every launch of one bench.py --headline-only step ({ng} dispatches incl. the untimed "
+        "gemm": {"kernel": f"{GEMM[0]}, ...>: every launch of one bench.py --headline-only step ({ng} dispatches incl. the untimed "
                            "trace pass)", "FETCH_SIZE_KiB_raw_avg": gfm, "WRITE_SIZE_KiB_avg": gwm},
         "command": "bash tools/profile_round.sh && python tools/profile_collect.py",
     },
