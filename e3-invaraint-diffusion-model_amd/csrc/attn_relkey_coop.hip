@@ -84,6 +84,24 @@ __device__ __forceinline__ void split8x2(const float (&x)[8], X8& hi, X8& lo) {
     }
 }
 
+// fp16 terms: the 4-instruction pair split of e3d_common.h
+__device__ __forceinline__ void split4x2(const f32x4 v, f16x4& hi, f16x4& lo) {
+    e3d_f16x2 h0, l0, h1, l1;
+    e3d_split2_f16(v[0], v[1], h0, l0);
+    e3d_split2_f16(v[2], v[3], h1, l1);
+    hi = f16x4{h0[0], h0[1], h1[0], h1[1]};
+    lo = f16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+__device__ __forceinline__ void split8x2(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        e3d_f16x2 h, l;
+        e3d_split2_f16(x[j], x[j + 1], h, l);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        lo[j] = l[0]; lo[j + 1] = l[1];
+    }
+}
+
 // acc += a.b from the three significant cross terms, smallest first ([0] = hi, [1] = lo)
 template <typename X8>
 __device__ __forceinline__ f32x16 mfma3(const X8 (&a)[2], const X8 (&b)[2], f32x16 acc) {

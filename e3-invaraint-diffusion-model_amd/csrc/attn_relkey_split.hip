@@ -54,6 +54,18 @@ __device__ __forceinline__ void split8(const float (&x)[8], X8 (&parts)[NS]) {
         }
 }
 
+template <int NS>
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8 (&parts)[NS]) {
+    static_assert(NS == 2, "fp16 terms exist as the two-term split only");
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        e3d_f16x2 h, l;
+        e3d_split2_f16(x[j], x[j + 1], h, l);
+        parts[0][j] = h[0]; parts[0][j + 1] = h[1];
+        parts[1][j] = l[0]; parts[1][j + 1] = l[1];
+    }
+}
+
 // one row's 64 head-dim values -> 4 k-blocks x NS parts (lane takes floats 16kb + 8h .. +7)
 template <int NS, typename X8>
 __device__ __forceinline__ void load_row_split(X8 (&f)[4][NS], const float* row_ptr, int half) {

@@ -81,11 +81,42 @@ __device__ __forceinline__ int mfma32_row(int reg, int half) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
-    // x * 0.5 * (1 + erf(x / sqrt(2)))  -- ATen's exact GELU
-    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    // x * 0.5 * (1 + erf(x / sqrt(2)))  -- ATen's exact (erf) GELU, evaluated branch-free as
+    //     relu(x) - 0.5 |x| erfc(|x| / sqrt(2)),   erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z)
+    // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erfc, i.e. <= 0.75e-7 |x| on the result: below fp32
+    // rounding of the GEMM sum it is applied to).  libm's erff costs ~30 VALU instructions per element once both of its
+    // range branches run in one wave -- 128 elements per lane in the 256x256 epilogue; this form is 14 with two
+    // transcendentals, and has no cancellation on the negative side (0.5 x erfc is formed directly).
+    const float ax = fabsf(x), z = ax * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    return fmaxf(x, 0.f) - 0.5f * ax * erfc_z;
 }
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// fp16 split of two fp32 values in 4 instructions: hi = v_cvt_pk_f16_f32 (RNE), the residuals by v_fma_mix_f32 reading
+// the packed halves directly (x - float(hi), exact), lo = v_cvt_pk_f16_f32.  The compiler's own lowering of the same
+// C expression takes 7 (separate conversions back to fp32); with the bf16 form at 6 this makes the f16x3 staging the
+// cheaper one.  hi is formed once and the residual reads that very register, so the two terms always complement
+// each other (no second, differently rounded evaluation of a fused producer -- see attn_relkey_coop.hip).
+typedef _Float16 e3d_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void e3d_split2_f16(float x0, float x1, e3d_f16x2& hi, e3d_f16x2& lo) {
+    e3d_f16x2 p;
+    p[0] = (_Float16)x0;
+    p[1] = (_Float16)x1;
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p), "v"(x1));
+    hi = p;
+    lo[0] = (_Float16)r0;
+    lo[1] = (_Float16)r1;
+}
+
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

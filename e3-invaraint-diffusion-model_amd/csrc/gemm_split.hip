@@ -63,6 +63,15 @@ __device__ __forceinline__ void split4(const f32x4 v, typename Vec<E>::x4 (&part
     }
 }
 
+template <>
+__device__ __forceinline__ void split4<2, _Float16>(const f32x4 v, f16x4 (&parts)[2]) {
+    e3d_f16x2 h0, l0, h1, l1;
+    e3d_split2_f16(v[0], v[1], h0, l0);
+    e3d_split2_f16(v[2], v[3], h1, l1);
+    parts[0] = f16x4{h0[0], h0[1], h1[0], h1[1]};
+    parts[1] = f16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
 // One operand's staging: NV float4-equivalents (4 consecutive k of one row) per thread.
 template <int ROWS, bool KMAJ, int NT = 512>
 struct Stager {
