@@ -293,6 +293,15 @@ class functional:
         return ops.residual_layernorm(x, residual, gamma, beta, eps)
 
     @staticmethod
+    def linear_residual_layernorm(x, weight, bias, residual, gamma, beta, eps, p_drop=0.0):
+        """BertSelfOutput / BertOutput: LayerNorm(dropout(x W^T + b) + residual).  Inference at small M takes the
+        fused skinny-GEMM finish (ops.linear_residual_layernorm); training and every other shape the three ops."""
+        if not p_drop and not _needs_grad(x, weight, bias, residual, gamma, beta):
+            return ops.linear_residual_layernorm(x, weight, bias, residual, gamma, beta, eps)
+        fn = functional
+        return fn.residual_layernorm(fn.dropout(fn.linear(x, weight, bias), p_drop), residual, gamma, beta, eps)
+
+    @staticmethod
     def adaln_gate(x, y, mod, branch, rows_per_cond):
         if _needs_grad(x, y, mod):
             return _AdaLNGate.apply(x, y, mod, branch, rows_per_cond)

@@ -155,8 +155,8 @@ def dropout_rates(module):
 
 # ----------------------------------------------------------------------------- executors
 def _attention_output(att, ctx, x, p_hidden=0.0):
-    o = F.dropout(F.linear(ctx, att.output.dense.weight, att.output.dense.bias), p_hidden)
-    return F.residual_layernorm(o, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, att.eps)
+    return F.linear_residual_layernorm(ctx, att.output.dense.weight, att.output.dense.bias, x, att.output.LayerNorm.weight,
+                                       att.output.LayerNorm.bias, att.eps, p_hidden)
 
 
 def run_self_attention(att, x, mask, B, L, drop=(0.0, 0.0)):
@@ -193,8 +193,8 @@ def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None, drop=
             raise ValueError("decoder layer needs encoder states")
         x = run_cross_attention(layer.crossattention, x, cross_kv, enc_mask, B, L, Lk, drop)
     inter = F.linear(x, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
-    o = F.dropout(F.linear(inter, layer.output.dense.weight, layer.output.dense.bias), drop[0])
-    return F.residual_layernorm(o, x, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps)
+    return F.linear_residual_layernorm(inter, layer.output.dense.weight, layer.output.dense.bias, x,
+                                       layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps, drop[0])
 
 
 def run_encoder(encoder, x, mask, B, L, enc=None, enc_mask=None, Lk=None, cross_kv=None):

@@ -28,12 +28,19 @@ class SELayer(nn.Module):
         nn.init.zeros_(self.adaLN_modulation[0].weight)
         nn.init.zeros_(self.adaLN_modulation[0].bias)
 
-    def run(self, x, c, mask, B, L):
-        """x [B*L,H]; c [B*L,H] (per token) or [B,H] (one conditioning row per item)."""
-        rows_per_cond = x.shape[0] // c.shape[0]
-        assert rows_per_cond in (1, L), (x.shape, c.shape)
+    def modulation(self, c):
+        """adaLN_modulation(c): [n,H] -> [n,6H] (shift, scale, gate of the attention branch, then of the MLP branch)."""
         m0, m2 = self.adaLN_modulation[0], self.adaLN_modulation[2]
-        mod = F.linear(F.linear(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
+        return F.linear(F.linear(c, m0.weight, m0.bias, ops.ACT_SILU), m2.weight, m2.bias)
+
+    def run(self, x, c, mask, B, L, mod=None):
+        """x [B*L,H]; c [B*L,H] (per token) or [B,H] (one conditioning row per item).  ``mod``: the rows
+        ``modulation(c)`` would give, computed by the caller ([B*L,6H], [B,6H], or ONE row [1,6H] shared by every
+        item: samplers precompute it per timestep) -- ``c`` is then not read."""
+        if mod is None:
+            mod = self.modulation(c)
+        rows_per_cond = x.shape[0] // mod.shape[0]
+        assert rows_per_cond in (1, L, B * L) and rows_per_cond * mod.shape[0] == x.shape[0], (x.shape, mod.shape)
         drop = bert.dropout_rates(self.attn)   # (hidden, attention) rates in training, zeros in eval
         att = bert.run_self_attention(self.attn, x, mask, B, L, drop)
         x = F.adaln_gate(x, att, mod, 0, rows_per_cond)

@@ -46,6 +46,7 @@ def _roctx():
 ROCTX_NAMES = {"attn_relkey": b"K1 relkey_attention_fwd", "attn_cross": b"K2 cross_attention_fwd",
                "attn_bwd": b"K3 attention_bwd", "adaln_gate": b"K4 adaln_gate",
                "residual_layernorm": b"K5 residual_layernorm", "embed_layernorm": b"K5 embed_layernorm",
+               "gemm_layernorm": b"K5 gemm_residual_layernorm",
                "gemm": b"K5 gemm_bias_act", "ddpm_step_wrap": b"K6 ddpm_step_wrap",
                "discrete_posterior": b"K7 discrete_posterior_sample", "discrete_q_sample": b"K7 discrete_q_sample"}
 
@@ -134,6 +135,28 @@ def set_gemm_mode(mode):
     return prev
 
 
+# Small-M launches (single-pocket / few-pocket sampling) go to the "skinny" kernels (csrc/gemm_skinny.hip: K cut across
+# workgroups so the whole chip streams the weight, partial tiles in a workspace, a second launch finishes the rows).  The
+# workspace must not be shared by launches that may run concurrently: one per (device, stream), grown on demand and kept.
+# E3D_GEMM_SKINNY=0 disables the path (A/B timing).
+SKINNY_MAX_M = 128 if os.environ.get("E3D_GEMM_SKINNY", "1") == "1" else 0
+_SKINNY_WS = {}
+
+
+def _skinny_workspace(device, M, N, K):
+    nbytes = hip.lib().e3d_gemm_skinny_workspace_bytes(M, N, K)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SKINNY_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        # (under a graph capture this comes from the graph's private pool and is kept alive here: replay-safe)
+        ws = _SKINNY_WS[key] = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _skinny_ok(terms, M, N, K, a):
+    return terms in (3, 19) and 0 < M <= SKINNY_MAX_M and N % 32 == 0 and K % 16 == 0 and a.stride(0) % 4 == 0
+
+
 def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
     """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view."""
     _chk(a, "gemm.a"); _chk(weight, "gemm.weight"); _chk(bias, "gemm.bias")
@@ -146,7 +169,12 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
     terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
     with _timed("gemm", (M, N, K, act)):
-        if terms == 0:
+        if _skinny_ok(terms, M, N, K, a) and out.stride(0) % 4 == 0:
+            ws = _skinny_workspace(a.device, M, N, K)
+            hip.check(hip.lib().e3d_gemm_skinny_f32_split(_p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0),
+                                                          M, N, K, act, terms, _p(ws), ws.numel(), _stream()),
+                      "e3d_gemm_skinny_f32_split")
+        elif terms == 0:
             hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
                                                       out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
         else:
@@ -268,6 +296,25 @@ def residual_layernorm(x, residual, gamma, beta, eps, want_s=False):
                                                        _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
     return (out, s) if want_s else out
 
+
+def linear_residual_layernorm(a, weight, bias, residual, gamma, beta, eps, mode=None):
+    """LayerNorm(a @ weight^T + bias + residual) * gamma + beta  (BertSelfOutput / BertOutput in eval mode).  Small M: the
+    second launch of the skinny GEMM does the row finish (bit-identical to gemm + residual_layernorm); otherwise the pair."""
+    M, K = a.shape
+    H = weight.shape[0]
+    terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
+    if not (_skinny_ok(terms, M, H, K, a) and H in (256, 512, 768, 1024) and a.stride(1) == 1):
+        return residual_layernorm(gemm(a, weight, bias, mode=mode), residual, gamma, beta, eps)
+    for t, n in ((a, "a"), (weight, "weight"), (bias, "bias"), (residual, "residual"), (gamma, "gamma"), (beta, "beta")):
+        _chk(t, "linear_residual_layernorm." + n)
+    assert weight.is_contiguous() and weight.shape[1] == K and (residual is None or (residual.is_contiguous() and residual.shape == (M, H)))
+    out = torch.empty((M, H), device=a.device, dtype=torch.float32)
+    ws = _skinny_workspace(a.device, M, H, K)
+    with _timed("gemm_layernorm", (M, H, K)):
+        hip.check(hip.lib().e3d_gemm_skinny_residual_layernorm_f32_split(
+            _p(a), a.stride(0), _p(weight), _p(bias), _p(residual), _p(gamma), _p(beta), eps, _p(out), M, H, K, terms,
+            _p(ws), ws.numel(), _stream()), "e3d_gemm_skinny_residual_layernorm_f32_split")
+    return out
 
 def adaln_gate(x, y, mod, branch, rows_per_cond):
     for n, t in (("x", x), ("y", y), ("mod", mod)):

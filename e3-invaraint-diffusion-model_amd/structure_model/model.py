@@ -58,14 +58,23 @@ class ConditionalBertForDiffusionBase(nn.Module):
             kv = [bert.project_cross_kv(layer.crossattention, x) for layer in self.decoder.layer]
         return ReceptorCache(x, kv, mask, B, L)
 
-    def decode(self, timestep, noised_ligand_angles, ligand_attention_masks, receptor: ReceptorCache):
-        """reference model.py:202-214."""
+    def timestep_modulation(self, timesteps):
+        """The part of the decoder that depends on the timestep alone (reference model.py:205-207: Fourier features ->
+        SELayer.adaLN_modulation): [n] timesteps -> [n,6H].  A sampler computes it once for its whole chain and hands
+        ``decode`` one row per step (``mod``) instead of ~12 small launches per step."""
+        temb = self.timestep_projector(timesteps.reshape(-1)).contiguous()
+        return self.timestep_emb.modulation(temb)
+
+    def decode(self, timestep, noised_ligand_angles, ligand_attention_masks, receptor: ReceptorCache, mod=None):
+        """reference model.py:202-214.  ``mod`` ([1,6H] or [B,6H]): ``timestep_modulation`` of this step's timestep,
+        if the caller has it already (``timestep`` is then not read)."""
         require_gpu(timestep, noised_ligand_angles, ligand_attention_masks)
         B, L = noised_ligand_angles.shape[:2]
         mask = ligand_attention_masks.contiguous().float()
         x = self.ligand_angle_emb.run(flat2d(noised_ligand_angles))
-        temb = self.timestep_projector(timestep.squeeze(dim=-1)).contiguous()   # [B,H]
-        x = self.timestep_emb.run(x, temb, mask, B, L)
+        if mod is None:
+            mod = self.timestep_modulation(timestep.squeeze(dim=-1))             # [B,6H]
+        x = self.timestep_emb.run(x, None, mask, B, L, mod=mod)
         x = bert.run_encoder(self.decoder, x, mask, B, L, enc=receptor.encoder_states,
                              enc_mask=receptor.mask, Lk=receptor.L, cross_kv=receptor.cross_kv)
         return self.angles_predictor.run(x).view(B, L, -1)

@@ -85,7 +85,7 @@ def p_sample(model, ligand_mask, ligand_angle_noise, receptor_seq, receptor_mask
 
 
 def _reverse_step(model, ligand_mask, x_t, receptor_seq, receptor_mask, receptor_angle, timestep,
-                  betas, noise, receptor_cache, out, wrap):
+                  betas, noise, receptor_cache, out, wrap, mod=None):
     tab = _tables(betas)
     if isinstance(timestep, int):
         t_index = timestep
@@ -96,7 +96,7 @@ def _reverse_step(model, ligand_mask, x_t, receptor_seq, receptor_mask, receptor
         t_index = int(t_unique.item())
     if receptor_cache is None:
         receptor_cache = model.encode_receptor(receptor_seq, receptor_angle, receptor_mask)
-    eps_hat = model.decode(timestep, x_t, ligand_mask, receptor_cache)
+    eps_hat = model.decode(timestep, x_t, ligand_mask, receptor_cache, mod=mod)
     sra = float(tab.sqrt_recip_alphas[t_index])
     beta = float(tab.betas[t_index])
     s1m = float(tab.sqrt_one_minus_alphas_cumprod[t_index])
@@ -117,15 +117,17 @@ class GraphedReverseStep:
     also the row of the [T,4] coefficient table read by ``e3d_ddpm_step_wrap_table``), the state
     ``self.x`` and the noise draw.  Results are bit-identical to the eager path for the same noise.
 
-    Opt-in (``use_graph=True`` / E3D_SAMPLE_GRAPH=1): measured on MI355X at B=1, L=64 a replay takes
-    3.9 ms per step against 3.8 ms of eager launches -- the kernel trace shows the GPU 100 % busy with
-    back-to-back kernels (mean gap 0.1 us), i.e. single-pocket sampling is bound by the latency of its
-    ~190 dependent small kernels (a 6-workgroup GEMM takes ~40 us), not by host launch cost."""
+    Default for chains of at most ops.SKINNY_MAX_M token rows (one or two pockets), ``use_graph=True`` /
+    E3D_SAMPLE_GRAPH=1 forces it, =0 turns it off.  Measured on MI355X, one 64-residue pocket (tools/bench_single.py):
+    round 1, 6-workgroup tiled GEMMs of ~29 us each: 3.9 ms per replayed step against 3.8 ms eager -- the GPU was 100 %
+    busy with dependent kernels, the graph had nothing to remove.  Round 2, K-sliced small-M GEMMs of ~7 us per product
+    (csrc/gemm_skinny.hip): eager launches are now host-bound at 2.4 ms per step, a replay takes 1.5 ms."""
 
-    def __init__(self, model, ligand_mask, cache, tab, x_like, wrap=True, draw=True):
-        """``draw``: the graph draws its own N(0,1) noise each replay; False: ``step`` takes the draw (parity tests)."""
+    def __init__(self, model, ligand_mask, cache, tab, x_like, wrap=True, draw=True, mod_table=None):
+        """``draw``: the graph draws its own N(0,1) noise each replay; False: ``step`` takes the draw (parity tests).
+        ``mod_table`` [T,6H]: row t = model.timestep_modulation(t), read on the device by the step index."""
         dev = x_like.device
-        self.model, self.mask, self.cache, self.wrap = model, ligand_mask, cache, wrap
+        self.model, self.mask, self.cache, self.wrap, self.mod_table = model, ligand_mask, cache, wrap, mod_table
         self.x = torch.empty_like(x_like)
         self.out = torch.empty_like(x_like)
         self.noise = torch.zeros_like(x_like)
@@ -145,7 +147,8 @@ class GraphedReverseStep:
             self._body()
 
     def _body(self):
-        eps_hat = self.model.decode(self.t, self.x, self.mask, self.cache)
+        mod = None if self.mod_table is None else self.mod_table.index_select(0, self.t[:1])
+        eps_hat = self.model.decode(self.t, self.x, self.mask, self.cache, mod=mod)
         if self.draw:
             self.noise.normal_()
         ops.ddpm_step_wrap_table(self.x, eps_hat.contiguous(), self.noise, self.coef, self.t, wrap=self.wrap, out=self.out)
@@ -164,7 +167,10 @@ class GraphedReverseStep:
 
 
 def _use_graph(x):
-    return os.environ.get("E3D_SAMPLE_GRAPH") == "1"
+    env = os.environ.get("E3D_SAMPLE_GRAPH")
+    if env in ("0", "1"):
+        return env == "1"
+    return x.shape[0] * x.shape[1] <= ops.SKINNY_MAX_M
 
 
 def trimmed_length(mask, multiple=32):
@@ -186,8 +192,8 @@ def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_se
                   trim_padding: bool = False) -> torch.Tensor:
     """Full reverse chain; returns [T/STEP, B, L, n_ft] (on the host like the reference,
     sample.py:101-144, unless ``return_device``).  ``noises`` [T/STEP,B,L,n_ft] injects the draws.
-    ``use_graph``: replay one captured HIP graph per step (opt-in, also E3D_SAMPLE_GRAPH=1 -- see
-    GraphedReverseStep for why it is not the default); falls back to eager launches if the capture fails."""
+    ``use_graph``: replay one captured HIP graph per step (None: by size, E3D_SAMPLE_GRAPH=0/1 overrides -- see
+    GraphedReverseStep); falls back to eager launches if the capture fails."""
     step = STEP if step is None else step
     tab = _tables(betas)
     order = list(reversed(range(0, total_timesteps, step)))
@@ -209,10 +215,15 @@ def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_se
                 noises = noises[:, :, :Ll]
     cache = model.encode_receptor(receptor_seq, receptor_angle, receptor_mask)
     traj = torch.empty((len(order),) + tuple(x.shape), device=x.device, dtype=torch.float32)
+    # what depends on the timestep alone, for the whole chain at once: row t of the table = timestep_modulation(t)
+    mod_rows = model.timestep_modulation(torch.tensor(order, device=x.device, dtype=torch.long))
+    mod_table = torch.zeros((total_timesteps, mod_rows.shape[1]), device=x.device, dtype=torch.float32)
+    mod_table[order] = mod_rows
     graphed = None
     if (_use_graph(x) if use_graph is None else use_graph) and len(order) > 4:
         try:
-            graphed = GraphedReverseStep(model, ligand_mask.contiguous().float(), cache, tab, x, draw=noises is None)
+            graphed = GraphedReverseStep(model, ligand_mask.contiguous().float(), cache, tab, x, draw=noises is None,
+                                         mod_table=mod_table)
         except Exception as e:   # noqa: BLE001 -- any capture problem: eager launches are always correct
             import warnings
             warnings.warn(f"HIP-graph capture of the reverse step failed ({type(e).__name__}: {e}); using eager launches")
@@ -223,7 +234,7 @@ def p_sample_loop(model: nn.Module, ligand_mask, ligand_angle_noise, receptor_se
             traj[n].copy_(x)
         else:
             x = _reverse_step(model, ligand_mask, x, None, None, None, i, tab,
-                              None if noises is None else noises[n], cache, traj[n], wrap=True)
+                              None if noises is None else noises[n], cache, traj[n], wrap=True, mod=mod_table[i:i + 1])
     if full_traj is not None:
         full_traj[:, :, :traj.shape[2]] = traj
         traj = full_traj

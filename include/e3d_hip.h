@@ -93,6 +93,30 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
                               float* out, float* lse, int B, int nh, int Lq, int Lk, int terms,
                               void* stream);
 
+/* The same product for M <= 128 rows (single-pocket / few-pocket sampling: BASELINE configs[0]), cut along K as well so
+ * that the whole chip streams the weight: one wave per (32 rows, 32 columns, K slice) writes a partial tile into the
+ * workspace, a second small launch sums the slices in slice order (deterministic) and applies bias and activation.
+ * Two launches on the given stream.  terms = 3 (bf16x3) or 19 (f16x3).  N % 32 == 0, K % 16 == 0, lda % 4 == 0,
+ * ldc % 4 == 0; A, W, bias, out 16-byte aligned.
+ * ``workspace``: device memory of >= e3d_gemm_skinny_workspace_bytes(M, N, K) bytes, 16-byte aligned, no initialisation
+ * needed, not shared by launches that may run concurrently (one per stream). */
+int64_t e3d_gemm_skinny_workspace_bytes(int M, int N, int K);
+int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const float* W, const float* bias, float* out,
+                              int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+/* Diagnostic switch (A/B timing, tools/lab/skinny_ab.py): the K-slicing plan of the kernels above -- waves per CU the
+ * plan aims for (times 2; default 3 = 1.5 per CU) and the shortest K slice (default 96).  Query the workspace size AFTER
+ * changing the plan.  Results differ between plans only by fp32 summation order. */
+void e3d_gemm_skinny_plan_select(int waves_per_cu_x2, int min_k_slice);
+/* BertSelfOutput / BertOutput in one call (transformers 4.38.2 modeling_bert.py: dense -> dropout(eval: identity) ->
+ * LayerNorm(hidden + input)):  out[M,H] = LayerNorm(A . W^T + bias + residual) * gamma + beta, the second launch of the
+ * product above doing the row finish.  Bit-identical to e3d_gemm_skinny_f32_split followed by
+ * e3d_residual_layernorm_fwd.  H in {256, 512, 768, 1024}; out is contiguous [M,H]; residual may be NULL. */
+int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
+                                                 const float* residual, const float* gamma, const float* beta, float eps,
+                                                 float* out, int M, int H, int K, int terms, void* workspace,
+                                                 int64_t workspace_bytes, void* stream);
+
 /* Diagnostic switch (A/B timing, tools/bench_kernels.py): which kernel form serves large-M forward launches of
  * e3d_gemm_bias_act_f32_split with terms = 3 -- 4 = persistent 256x256 (default), 3 = 256x256 with interleaved
  * staging, 1 = classic 256x256 loop, 0 = 256x128.  Results are identical in every form (same products, same

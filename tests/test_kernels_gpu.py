@@ -211,9 +211,10 @@ def test_adaln_gate(pkg, hip, rows_per_cond, branch):
     assert rel_err(got, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M", [48, 1040])     # one wave per row (M <= 512) / LDS-staged W^T
 @pytest.mark.parametrize("Fin,H", [(8, 768), (20, 768), (20, 256)])
-def test_embed_layernorm(pkg, hip, Fin, H):
-    M, L = 48, 16
+def test_embed_layernorm(pkg, hip, Fin, H, M):
+    L = 16
     x = torch.randn(M, Fin, generator=g(1))
     w, b = torch.randn(H, Fin, generator=g(2)), torch.randn(H, generator=g(3))
     ga, be = 1 + 0.1 * torch.randn(H, generator=g(4)), torch.randn(H, generator=g(5))
@@ -223,6 +224,9 @@ def test_embed_layernorm(pkg, hip, Fin, H):
     assert rel_err(pkg.ops.embed_layernorm(d(x), d(w), d(b), d(ga), d(be), 1e-12), ref) < 2e-6
     got = pkg.ops.embed_layernorm(d(x), d(w), d(b), d(ga), d(be), 1e-12, d(add), L)
     assert rel_err(got, ref + add.repeat_interleave(L, 0)) < 2e-6
+    if M > 512:   # the two forms do the same arithmetic in the same order
+        few = pkg.ops.embed_layernorm(d(x[:48]), d(w), d(b), d(ga), d(be), 1e-12, d(add[:3]), L)
+        assert torch.equal(few, got[:48])
 
 
 @pytest.mark.parametrize("n_out", [8, 20])
@@ -425,3 +429,77 @@ def test_f16x3_range_contract(pkg, hip):
     got4 = pkg.ops.gemm(a4.to(DEV), w.to(DEV), None, mode="f16x3")
     assert not torch.isfinite(got4[3]).all() and torch.isfinite(got4[4:]).all()
     assert torch.isfinite(pkg.ops.gemm(a4.to(DEV), w.to(DEV), None, mode="bf16x6")).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (64, 768, 768), (64, 2304, 768), (33, 768, 1024), (128, 4608, 768),
+                                   (100, 1024, 3072), (64, 768, 48)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("f16x3", 5e-6)])
+def test_gemm_skinny_split_k(pkg, hip, M, N, K, act, mode, tol):
+    """The small-M kernels (one wave per 32x32 tile and K slice, slices summed in slice order by a second launch):
+    against fp64; run-to-run bit-identical; a strided activation view; rows past M; launches of different shapes share
+    one workspace back to back (nothing of an earlier shape's slabs may show)."""
+    assert M <= pkg.ops.SKINNY_MAX_M
+    wide = torch.randn(M, K + 32, generator=g(M + N))
+    a = wide[:, 16:16 + K]
+    w = torch.randn(N, K, generator=g(K)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(7))
+    ref = F.linear(a.double(), w.double(), b.double())
+    ref = {0: lambda x: x, 1: F.gelu, 2: F.silu}[act](ref).float()
+    ad, wd, bd = wide.to(DEV)[:, 16:16 + K], w.to(DEV), b.to(DEV)
+    outs = [pkg.ops.gemm(ad, wd, bd, act, mode=mode).clone() for _ in range(4)]
+    assert rel_err(outs[0], ref) < tol
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    # same maths as the tiled kernel (other summation order): fp32 rounding apart
+    prev = pkg.ops.SKINNY_MAX_M
+    pkg.ops.SKINNY_MAX_M = 0
+    try:
+        tiled = pkg.ops.gemm(ad, wd, bd, act, mode=mode) if N % 128 == 0 and K % 32 == 0 else None
+    finally:
+        pkg.ops.SKINNY_MAX_M = prev
+    if tiled is not None:
+        assert rel_err(outs[0], tiled) < 2e-6
+
+
+@pytest.mark.parametrize("M,H,K", [(64, 768, 768), (64, 768, 1024), (33, 256, 512), (128, 1024, 3072), (5, 512, 64)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("f16x3", 5e-6)])
+def test_gemm_skinny_residual_layernorm(pkg, hip, M, H, K, mode, tol):
+    """BertSelfOutput / BertOutput in one call (dense -> + residual -> LayerNorm): bit-identical to the unfused pair
+    (skinny GEMM, then the LayerNorm kernel), against fp64, with and without a residual."""
+    a = torch.randn(M, K, generator=g(M + K))
+    w = torch.randn(H, K, generator=g(H)) / math.sqrt(K)
+    b, res = torch.randn(H, generator=g(1)), torch.randn(M, H, generator=g(2))
+    gamma, beta = torch.rand(H, generator=g(3)) + 0.5, torch.randn(H, generator=g(4))
+    ad, wd, bd, rd, gd, be = (t.to(DEV) for t in (a, w, b, res, gamma, beta))
+    for r_cpu, r_dev in ((res, rd), (None, None)):
+        pre = F.linear(a.double(), w.double(), b.double()) + (0 if r_cpu is None else r_cpu.double())
+        ref = F.layer_norm(pre, (H,), gamma.double(), beta.double(), 1e-12).float()
+        fused = pkg.ops.linear_residual_layernorm(ad, wd, bd, r_dev, gd, be, 1e-12, mode=mode)
+        pair = pkg.ops.residual_layernorm(pkg.ops.gemm(ad, wd, bd, mode=mode), r_dev, gd, be, 1e-12)
+        assert torch.equal(fused, pair)
+        assert rel_err(fused, ref) < 4 * tol
+    # larger M: the same entry point falls back to the two ops
+    big = torch.randn(256, K, device=DEV)
+    assert torch.equal(pkg.ops.linear_residual_layernorm(big, wd, bd, None, gd, be, 1e-12, mode=mode),
+                       pkg.ops.residual_layernorm(pkg.ops.gemm(big, wd, bd, mode=mode), None, gd, be, 1e-12))
+
+
+def test_gemm_skinny_under_load_every_word(pkg, hip):
+    """The small-M kernels while a large GEMM on a second stream keeps the CUs busy: many launches back to back on
+    fresh data, every output word compared."""
+    M, N, K = 64, 2304, 768
+    big_a = torch.randn(16384, 768, device=DEV)
+    big_w = torch.randn(768, 768, device=DEV) / 27.7
+    side = torch.cuda.Stream()
+    w = (torch.randn(N, K, generator=g(3)) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g(4)).to(DEV)
+    bad = 0
+    for it in range(60):
+        a = torch.randn(M, K, device=DEV)
+        with torch.cuda.stream(side):
+            pkg.ops.gemm(big_a, big_w, None, mode="bf16x3")
+        got = pkg.ops.gemm(a, w, b, mode="f16x3")
+        ref = torch.addmm(b.double(), a.double(), w.double().t()).float()
+        bad += int(((got - ref).abs() > 2e-5 * ref.abs().max()).sum())
+    torch.cuda.synchronize()
+    assert bad == 0, bad
