@@ -122,7 +122,9 @@ def _packed(owner, name, tensors):
     and autograd is on): a fresh differentiable torch.cat, so the packed gradient is split back
     onto query/key/value by autograd."""
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        return torch.cat(list(tensors), dim=0)
+        out = torch.cat(list(tensors), dim=0)
+        out._e3d_parts = list(tensors)    # autograd.deferred_weight_grads writes the row blocks' gradients straight
+        return out                        # into these parameters instead of through cat's backward
     key = ops.weight_key(*tensors)    # includes the optimizer-step generation: fused optimizers do not bump _version
     cache = owner.__dict__.setdefault("_e3d_pack", {})
     hit = cache.get(name)

@@ -140,6 +140,13 @@ struct Stager {
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(img + s * part_bytes + off[i]) = p[s];
     }
+    // sum of the item's 4 values with the same reduction-tail masking as store_item (K-major items)
+    __device__ __forceinline__ float masked_sum(int i, const f32x4& v, int k0, int K) const {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (!KMAJ || k0 + kbase[i] + j < K) ? v[j] : 0.f;
+        return (t[0] + t[1]) + (t[2] + t[3]);
+    }
     template <int NS, typename E>
     __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes, int k0, int K) const {
 #pragma unroll
@@ -152,14 +159,17 @@ struct Stager {
 // WN = waves along N (64 columns each).  WN = 1 (128 x 64 tiles of two waves, three workgroups per CU, twice the grid)
 // was measured for the medium-M launches of training and trimmed sampling and is not dispatched: 45 us against 31 us
 // for the 128 x 128 form at M = 4096, N = K = 768 (two waves per workgroup hide even less of the k-step chain).
+// The workgroup body, shared by the plain kernel (one problem; block y = split-K slice) and the grouped
+// weight-gradient kernel below (block -> (problem, tile), no split-K).  ``colsum_out`` (K-major x K-major layout only):
+// the workgroups of tile column 0 also write out-row sums of A over the reduction index -- the bias gradient
+// sum_m dz[m][n] of a linear layer, whose weight gradient dz^T . x this layout computes -- from the values they stage
+// anyway.  ``accumulate``: out += instead of out = (a weight used twice in one backward pass).
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
-                                                         const float* __restrict__ Bm, int64_t ldb,
-                                                         const float* __restrict__ bias,
-                                                         float* __restrict__ out, int64_t ldc, int M,
-                                                         int N, int K_total, int tiles_m, int tiles_n,
-                                                         int k_chunk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const float* __restrict__ A, int64_t lda,
+                                                const float* __restrict__ Bm, int64_t ldb,
+                                                const float* __restrict__ bias, float* __restrict__ out, int64_t ldc,
+                                                int M, int N, int K_total, int tiles_m, int tiles_n, int k_chunk,
+                                                int bx, int by, int ny, float* __restrict__ colsum_out, int accumulate) {
     constexpr int NBUF = NS == 2 ? 2 : 1;
     constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
@@ -167,10 +177,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
 
     // split-K (weight gradients: few output tiles, long reduction over the tokens): block y reduces
     // k in [k_begin, K) and adds its partial tile atomically into the zero-initialised output
-    const int k_begin = blockIdx.y * k_chunk;
+    const int k_begin = by * k_chunk;
     const int K = min(K_total, k_begin + k_chunk);
-    const bool split = gridDim.y > 1;
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const bool split = ny > 1;
+    const int lid = bx;   // logical tile index (the callers apply xcd_remap)
     const int tm = lid / tiles_n, tn = lid % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -192,8 +202,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
+    constexpr bool CS = A_KMAJ && B_KMAJ;          // row sums of A over k ride along (cheap: 3 adds per staged item)
+    float cs[Stager<BM, A_KMAJ, NT>::NV];
+#pragma unroll
+    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] = 0.f;
     sa.load(ra, k_begin, K);
     sb.load(rb, k_begin, K);
+    if (CS) {
+#pragma unroll
+        for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, ra[i], k_begin, K);
+    }
     sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin, K);
     sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin, K);
     __syncthreads();
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
 #pragma unroll
                     for (int i = 0; i < NA_; ++i)
                         if (i * 4 / NA_ == g) {
+                            if (CS) cs[i] += sa.masked_sum(i, ra[i], k_begin + (kt + 1) * BK, K);
                             sa.template store_item<NS, E>(i, ra[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
                             sa.load_item(i, ra[i], k2, K);
                         }
@@ -271,6 +290,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
         } else {
             __syncthreads();  // everyone done reading the single buffer
             if (more) {
+                if (CS) {
+#pragma unroll
+                    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, ra[i], k_begin + (kt + 1) * BK, K);
+                }
                 sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
                 sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
             }
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int col = col0 + wc * 64 + n * 32 + l31;
-        const float bv = (bias && col < N && blockIdx.y == 0) ? bias[col] : 0.f;
+        const float bv = (bias && col < N && by == 0) ? bias[col] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -291,12 +314,71 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
                 if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                 if (ACT == E3D_ACT_SILU) v = silu(v);
                 if (row < M && col < N) {
-                    if (split) atomicAdd(out + (int64_t)row * ldc + col, v);
-                    else out[(int64_t)row * ldc + col] = v;
+                    float* o = out + (int64_t)row * ldc + col;
+                    if (split) atomicAdd(o, v);
+                    else *o = accumulate ? *o + v : v;
                 }
             }
         }
     }
+    if (CS && colsum_out && tn == 0) {
+        // 8 threads (the 4-k groups of a k-tile) hold partial sums of each row: meet in LDS, summed in a fixed order.
+        // (every wave is past its last fragment read: the k loop ends with a workgroup barrier)
+        float* red = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+        for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) {
+            const int f = tid + NT * i;
+            red[(f / BM) * BM + f % BM] = cs[i];
+        }
+        __syncthreads();
+        if (tid < BM && row0 + tid < M) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += red[g * BM + tid];
+            float* o = colsum_out + row0 + tid;
+            if (split) atomicAdd(o, v);
+            else *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ Bm, int64_t ldb,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ out, int64_t ldc, int M,
+                                                         int N, int K_total, int tiles_m, int tiles_n,
+                                                         int k_chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
+                                                        tiles_n, k_chunk, xcd_remap(blockIdx.x, tiles_m * tiles_n),
+                                                        blockIdx.y, gridDim.y, nullptr, 0);
+}
+
+// Weight gradients of up to 64 linear layers of ONE shape in one launch: problem p computes dW_p[N,K] = dz_p^T . x_p
+// (dz_p [M,N], x_p [M,K]: both K-major in this kernel's terms, reduction over the M tokens) and db_p[N] = column sums
+// of dz_p.  A layer alone has too few output tiles for the chip (18 of 256x128 for a 768x768 weight) and had to cut the
+// reduction into split-K slices that meet through atomics on a zeroed output (82 TFLOP/s at M = 4096); a model's layers
+// together fill it several times over with whole reductions (230-270 TFLOP/s measured on the same kernel body:
+// tools/lab/wgrad_steady.py), without atomics or memsets: deterministic.
+struct WgradGroup {
+    const float* dz[64];
+    const float* x[64];
+    float* dw[64];
+    float* db[64];
+    unsigned long long accumulate;   // bit p: dW_p / db_p += (the weight already holds a gradient)
+};
+
+template <int NS>
+__global__ __launch_bounds__(512) void gemm_wgrad_grouped_kernel(const WgradGroup g, int64_t ldz, int64_t ldx, int N, int K,
+                                                                 int M, int tiles_m, int tiles_n, int count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tiles = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, tiles * count);
+    const int p = lid / tiles;
+    gemm_split_body<NS, E3D_ACT_NONE, true, true, 4, 2, __bf16>(smem_raw, g.dz[p], ldz, g.x[p], ldx, nullptr, g.dw[p], K, N,
+                                                                 K, M, tiles_m, tiles_n, M, lid - p * tiles, 0, 1, g.db[p],
+                                                                 (int)((g.accumulate >> p) & 1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -876,6 +958,38 @@ extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kma
         return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
     }
     return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+}
+
+extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const float* const* x, float* const* dw,
+                                                float* const* db, uint64_t accumulate_bits, int count, int64_t ldz,
+                                                int64_t ldx, int N, int K, int M, int terms, void* stream) {
+    E3D_REQUIRE(dz && x && dw && count >= 1 && count <= 64, "gemm_wgrad_grouped: 1..64 problems (count=%d)", count);
+    E3D_REQUIRE(M > 0 && N > 0 && K > 0 && ldz >= N && ldx >= K, "gemm_wgrad_grouped: bad shape N=%d K=%d M=%d ldz=%lld ldx=%lld",
+                N, K, M, (long long)ldz, (long long)ldx);
+    E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "gemm_wgrad_grouped: terms must be 3, 6 or 19 (got %d)", terms);
+    WgradGroup g;
+    for (int p = 0; p < 64; ++p) {
+        const int q = p < count ? p : 0;
+        E3D_REQUIRE(dz[q] && x[q] && dw[q], "gemm_wgrad_grouped: null pointer in problem %d", q);
+        g.dz[p] = dz[q]; g.x[p] = x[q]; g.dw[p] = dw[q]; g.db[p] = db ? db[q] : nullptr;
+    }
+    g.accumulate = accumulate_bits;
+    const int tiles_m = (N + 255) / 256, tiles_n = (K + 127) / 128;
+    E3D_REQUIRE((int64_t)tiles_m * tiles_n * count < (1ll << 30), "gemm_wgrad_grouped: too many tiles");
+    const dim3 grid(tiles_m * tiles_n * count), block(512);
+    hipStream_t s = (hipStream_t)stream;
+    if (terms == 3) {
+        const size_t lds = (size_t)2 * 2 * (256 + 128) * ROW_B;
+        static std::atomic<uint64_t> lds_ok{0};
+        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<2>, lds);
+        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<2>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+    } else {   // fp32-grade: three bf16 terms, six products (the K-major layouts have no fp16 form)
+        const size_t lds = (size_t)1 * 3 * (256 + 128) * ROW_B;
+        static std::atomic<uint64_t> lds_ok{0};
+        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<3>, lds);
+        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<3>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+    }
+    return e3d_launch_status("e3d_gemm_wgrad_grouped_f32_split");
 }
 
 extern "C" int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W,

@@ -145,6 +145,11 @@ class GradientAverager:
         if self._pending[i] == 0:
             self._launch(i)
 
+    def mark_ready(self, p):
+        """For gradients written outside autograd's accumulation (autograd.deferred_weight_grads(on_param=...)): the
+        post-accumulate-grad hook never fires for them."""
+        self._on_grad(p)
+
     def _launch(self, i):
         self._handles[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True)
 

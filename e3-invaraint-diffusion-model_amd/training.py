@@ -25,7 +25,7 @@ def adamw(params, lr, weight_decay):
         return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
 
 
-from . import ops, sharding
+from . import autograd, ops, sharding
 
 
 def move_batch(batch, device):
@@ -52,6 +52,7 @@ class BestCheckpoint:
 # sequence_model/train_model.py:114): bf16 products.  bf16x3 is 500x finer per product and is the arithmetic every
 # backward kernel of this package exists in; the inference default (f16x3) has forward kernels only.
 TRAIN_ARITHMETIC = "bf16x3"
+DEFER_WEIGHT_GRADS = os.environ.get("E3D_DEFER_WGRAD", "1") == "1"   # autograd.deferred_weight_grads in the step
 
 
 def fit(model, train_loader, val_loader=None, *, max_epochs, min_epochs=0, gradient_clip=1.0, device="cuda:0",
@@ -89,7 +90,13 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             loss = model.training_step(batch, batch_idx)
             optim.zero_grad(set_to_none=True)
             averager.prepare()                       # grads as views of the all-reduce buckets (no-op for one process)
-            loss.backward()
+            # the weight gradients of all linear layers are computed together when the block ends (grouped launches,
+            # written into .grad, i.e. into the all-reduce buckets); E3D_DEFER_WGRAD=0: layer by layer inside backward
+            if DEFER_WEIGHT_GRADS:
+                with autograd.deferred_weight_grads(on_param=averager.mark_ready):
+                    loss.backward()
+            else:
+                loss.backward()
             averager.average()                       # RCCL all-reduce (no-op for one process)
             if gradient_clip:
                 torch.nn.utils.clip_grad_norm_(params, gradient_clip)   # global norm of the averaged grads

@@ -231,6 +231,19 @@ int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kmajor, const 
                                int b_kmajor, const float* bias, float* out, int64_t ldc, int M, int N,
                                int K, int act, int terms, void* stream);
 
+/* Weight and bias gradients of up to 64 linear layers of ONE shape in one launch (the backward of nn.Linear for every
+ * layer of a model at once: torch.autograd computes them layer by layer, Lightning training_step as above):
+ *   dW_p[N,K] (contiguous) = dz_p^T . x_p,   db_p[N] = column sums of dz_p      p = 0 .. count-1
+ * dz_p [M,N] (row stride ldz), x_p [M,K] (row stride ldx); the reduction runs over the M token rows.  A single layer
+ * has too few output tiles for the chip and needs split-K with atomics on a zeroed output; a model's layers together
+ * fill it with whole reductions: no atomics, no memsets, deterministic.
+ * dz, x, dw, db: HOST arrays of ``count`` device pointers (db may be NULL, or hold NULL entries: no bias gradient).
+ * accumulate_bits: bit p set -> dW_p and db_p are added to (a weight that already holds a gradient), else overwritten.
+ * Two problems of one launch must not share an output.  terms = 3 (bf16x3), 6 or 19 (bf16x6). */
+int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const float* const* x, float* const* dw, float* const* db,
+                                     uint64_t accumulate_bits, int count, int64_t ldz, int64_t ldx, int N, int K, int M,
+                                     int terms, void* stream);
+
 /* Backward of e3d_relkey_attn_fwd.  out / lse are the forward's outputs, dout [B,Lq,nh*64].
  * Writes dq, dk, dv (strided like q, k, v) and, with dist_emb, d_dist_emb [2P-1,64] (overwritten).
  * workspace: e3d_relkey_attn_bwd_workspace_floats(...) floats (materialised P and dS tiles + the

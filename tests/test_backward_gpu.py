@@ -55,6 +55,46 @@ def test_linear_backward(pkg, hip, Fm, M, N, K, act, mode, tol):
     assert rel_err(bd.grad, br.grad.float()) < 1e-5
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 1e-5)])
+@pytest.mark.parametrize("N,K,M,count", [(768, 768, 4096, 5), (300, 160, 1000, 3), (2304, 768, 515, 2), (64, 1024, 96, 64)])
+def test_grouped_weight_gradients(pkg, hip, N, K, M, count, mode, tol):
+    """e3d_gemm_wgrad_grouped_f32_split: dW_p = dz_p^T x_p and db_p = column sums of dz_p for ``count`` layers of one
+    shape in one launch, against fp64: ragged tiles (N, K not multiples of the 256x128 tile), a token count that is
+    not a multiple of the k-step, dz given as a column block of a wider matrix (packed QKV), the accumulate bit,
+    problems without a bias, and run-to-run bit-identity (no atomics)."""
+    import ctypes
+    lib = pkg.hip.lib()
+    terms = pkg.ops.GEMM_MODES[mode]
+    wide = [torch.randn(M, N + 64, generator=g(10 + p)).to(DEV) for p in range(count)]
+    dz = [w[:, 32:32 + N] for w in wide]
+    x = [torch.randn(M, K, generator=g(100 + p)).to(DEV) for p in range(count)]
+    dw = [torch.full((N, K), float(p), device=DEV) for p in range(count)]     # old contents: kept only where the bit is set
+    db = [torch.full((N,), -float(p), device=DEV) for p in range(count)]
+    bits = sum(1 << p for p in range(count) if p % 3 == 1)
+
+    def run(with_bias=True):
+        arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])   # noqa: E731
+        pkg.hip.check(lib.e3d_gemm_wgrad_grouped_f32_split(arr(dz), arr(x), arr(dw), arr(db) if with_bias else None, bits,
+                                                           count, dz[0].stride(0), x[0].stride(0), N, K, M, terms,
+                                                           torch.cuda.current_stream().cuda_stream), "grouped wgrad")
+    run()
+    first = [t.clone() for t in dw + db]
+    for p in range(count):
+        want_w = dz[p].double().t() @ x[p].double()
+        want_b = dz[p].double().sum(0)
+        if bits >> p & 1:
+            want_w, want_b = want_w + p, want_b - p
+        assert rel_err(dw[p], want_w.float()) < tol, p
+        assert rel_err(db[p], want_b.float()) < 1e-5, p
+    for t, p in zip(dw + db, list(range(count)) * 2):       # same launch again on the same inputs: bit-identical
+        t.fill_(float(p) if t.dim() == 2 else -float(p))
+    run()
+    assert all(torch.equal(a, b) for a, b in zip(first, dw + db))
+    keep = [t.clone() for t in db]
+    run(with_bias=False)
+    assert all(torch.equal(a, b) for a, b in zip(keep, db))
+
+
 def test_gemm_general_odd_reduction_and_strided(pkg, hip):
     from e3diff_amd.autograd import gemm_general
     M, N, K = 70, 200, 45          # K-major operands: any K, any N
@@ -181,9 +221,17 @@ def test_cross_attention_backward_rectangular(pkg, hip, Fm):
     assert rel_err(kd.grad, kr.grad.float()) < 2e-5
 
 
-def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol):
+def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
+    """``defer``: the weight / bias gradients of the linear layers computed at the end of the backward pass, grouped by
+    shape (autograd.deferred_weight_grads) instead of layer by layer inside it."""
     model.zero_grad(set_to_none=True)
-    loss_dev.backward()
+    if defer:
+        from e3diff_amd.autograd import deferred_weight_grads
+        with deferred_weight_grads() as q:
+            loss_dev.backward()
+            assert len(q.pending) > 10     # the linear layers really took the deferred path
+    else:
+        loss_dev.backward()
     ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     loss_ref = loss_ref_fn(ref_sd)
     loss_ref.backward()
@@ -208,8 +256,9 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol):
     return max(worst.values())
 
 
+@pytest.mark.parametrize("defer", [False, True])
 @pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4)])   # measured on MI355X: 4.0e-6 / 4.1e-5
-def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, capsys):
+def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, defer, capsys):
     """Whole structure model, loss of the reference (wrapped L1 x4 + smooth-L1 x4), every parameter
     gradient against CPU autograd of the oracle."""
     from e3diff_amd.bert import BertConfig
@@ -238,14 +287,15 @@ def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, cap
                                 pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
             return ostr.loss_terms(pred, batch["known_noise"], pk["ligand_attn_mask"]).mean()
 
-        worst = _grad_compare(model, sd, loss, ref_loss, tol)
+        worst = _grad_compare(model, sd, loss, ref_loss, tol, defer)
     finally:
         pkg.ops.set_gemm_mode(prev); pkg.ops.set_attn_mode(prev_a)
     with capsys.disabled():
-        print(f"\n[structure grads, {mode}] worst relative gradient error {worst:.2e}")
+        print(f"\n[structure grads, {mode}{', grouped weight gradients' if defer else ''}] worst relative gradient error {worst:.2e}")
 
 
-def test_sequence_training_step_gradients_match_oracle(pkg, hip, capsys):
+@pytest.mark.parametrize("defer", [False, True])    # True: incl. ligand_feature_emb, whose weights are used twice
+def test_sequence_training_step_gradients_match_oracle(pkg, hip, defer, capsys):
     from e3diff_amd.bert import BertConfig
     from e3diff_amd.sequence_model.model import PeptideDiff
     L, B = 64, 3
@@ -273,7 +323,7 @@ def test_sequence_training_step_gradients_match_oracle(pkg, hip, capsys):
                                 pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
             return oseq.get_loss(pred, pk, noised)[0]
 
-        worst = _grad_compare(model, sd, loss, ref_loss, 2e-4)
+        worst = _grad_compare(model, sd, loss, ref_loss, 2e-4, defer)
     finally:
         pkg.ops.set_gemm_mode(prev); pkg.ops.set_attn_mode(prev_a)
     # parameters the forward never touches keep no gradient (reference quirk)

@@ -56,7 +56,11 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
             batch_ = pk
         loss = model.training_step(batch_)
         optim.zero_grad(set_to_none=True)
-        loss.backward()
+        if pkg.training.DEFER_WEIGHT_GRADS:        # as training.fit does: weight gradients grouped at the end of backward
+            with pkg.autograd.deferred_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         optim.step()
         return loss
