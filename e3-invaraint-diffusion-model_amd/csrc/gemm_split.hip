@@ -164,14 +164,14 @@ struct Stager {
 // the workgroups of tile column 0 also write out-row sums of A over the reduction index -- the bias gradient
 // sum_m dz[m][n] of a linear layer, whose weight gradient dz^T . x this layout computes -- from the values they stage
 // anyway.  ``accumulate``: out += instead of out = (a weight used twice in one backward pass).
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
 __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const float* __restrict__ A, int64_t lda,
                                                 const float* __restrict__ Bm, int64_t ldb,
                                                 const float* __restrict__ bias, float* __restrict__ out, int64_t ldc,
                                                 int M, int N, int K_total, int tiles_m, int tiles_n, int k_chunk,
                                                 int bx, int by, int ny, float* __restrict__ colsum_out, int accumulate) {
     constexpr int NBUF = NS == 2 ? 2 : 1;
-    constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
+    constexpr int BM = WM * 64, BN = WN * 32 * TN, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
     constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
 
@@ -193,11 +193,11 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     sa.init(A, lda, row0, M, tid);
     sb.init(Bm, ldb, col0, N, tid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
@@ -217,7 +217,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     __syncthreads();
 
     const int nk = (K - k_begin + BK - 1) / BK;
-    const int a_row = wr * 64 + l31, b_row = wc * 64 + l31;   // fragment rows of m / n tile 0 (tile 1: +32)
+    const int a_row = wr * 64 + l31, b_row = wc * (32 * TN) + l31;   // fragment rows of m / n tile 0 (tile 1: +32)
     int cur = 0;
     // Two buffers: interleaved staging as in the 256x256 kernel below -- each of the 4 MFMA groups of a k-step is
     // preceded by its share of the staging of tile t+1 (split + ds_write of a register item, then the re-issue of
@@ -241,14 +241,14 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            typename Vec<E>::x8 fa[NS][2], fb[NS][2];
+            typename Vec<E>::x8 fa[NS][2], fb[NS][TN];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
                     fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < TN; ++n)
                     fb[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
             }
 #pragma unroll
@@ -270,7 +270,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
                         }
                 }
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
+                for (int n = 0; n < TN; ++n) {
                     // smallest terms first
                     if (NS == 3) {
                         acc[m][n] = mma16(fa[1][m], fb[1][n], acc[m][n]);
@@ -302,8 +302,8 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     }
 
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int col = col0 + wc * 64 + n * 32 + l31;
+    for (int n = 0; n < TN; ++n) {
+        const int col = col0 + wc * (32 * TN) + n * 32 + l31;
         const float bv = (bias && col < N && by == 0) ? bias[col] : 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     }
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
                                                          int N, int K_total, int tiles_m, int tiles_n,
                                                          int k_chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
+    gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
                                                         tiles_n, k_chunk, xcd_remap(blockIdx.x, tiles_m * tiles_n),
                                                         blockIdx.y, gridDim.y, nullptr, 0);
 }
@@ -796,7 +796,7 @@ int launch256(const float* A, int64_t lda, const float* W, const float* bias, fl
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s);
 
@@ -829,8 +829,8 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
             (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
             return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, s);
     }
-    // general kernel, two tile forms: 1 = 256x128 (8 waves, one workgroup per CU: 96 KB of LDS), 2 = 128x128 (4 waves,
-    // two per CU).  Both are bound by the latency of a workgroup's own k-step chain at these sizes, so the choice is a
+    // general kernel, three tile forms: 1 = 256x128 (8 waves, one workgroup per CU: 96 KB of LDS), 2 = 128x128 (4 waves,
+    // two per CU), 3 = 128x128 on 8 waves (each 64x32; forward and input-gradient layouts of the 2-term kernels).  Both are bound by the latency of a workgroup's own k-step chain at these sizes, so the choice is a
     // matter of rounds (tools/lab/gemm_forms_ab.py, K = 768: a 128x128 workgroup alone on its CU takes ~29 us, ~45 us
     // when it shares the CU; a 256x128 one ~37 us): E3D_GEMM_FORM / e3d_gemm_general_select force a form.
     if (g_general_form < 0) {
@@ -838,28 +838,40 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         g_general_form = e ? atoi(e) : 0;
     }
     int form = g_general_form;
-    if (form != 1 && form != 2) {
+    if (form != 1 && form != 2 && form != 3) {
         const int64_t g256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), g128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
         const int64_t cus = e3d_cu_count();
         if (NS != 2) form = g256 < 128 && !A_KMAJ && !B_KMAJ ? 2 : 1;       // 3-term kernels: as measured in round 1
         else if (A_KMAJ && B_KMAJ) form = 1;                                // weight gradients (split-K over one resident round): +4 %
-        else if (g128 <= cus) form = 2;
-        else if (g256 <= cus) form = 1;
-        else form = 45 * ((g128 + 2 * cus - 1) / (2 * cus)) < 37 * ((g256 + cus - 1) / cus) ? 2 : 1;
+        else if (A_KMAJ) form = g128 <= cus ? 2 : (g256 <= cus ? 1 : (45 * ((g128 + 2 * cus - 1) / (2 * cus)) < 37 * ((g256 + cus - 1) / cus) ? 2 : 1));
+        // forward / input-gradient layouts: the 8-wave 128x128 form (3) against the 256x128 form (1) by rounds of one
+        // workgroup per CU (measured at K = 768: ~25 us and ~38 us per round; form 3 at M = 4096: N = 768 26.8 us
+        // against 32.5 (4-wave 128x128) / 36.9, N = 2304 70 against 81; M = 8192: form 1 by 4 %)
+        else form = 25 * ((g128 + cus - 1) / cus) <= 38 * ((g256 + cus - 1) / cus) ? 3 : 1;
     }
+    if constexpr (NS == 2 && !A_KMAJ) {
+        // form 3: the 128x128 tile on EIGHT waves (2 x 4, each 64x32): two waves per SIMD cover each other's staging
+        if (form == 3) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 4, E, 1>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
+    }
+    if (form == 3) form = 2;
     if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
     return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, s);
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, hipStream_t s) {
-    constexpr int BM = WM * 64, BNt = WN * 64;
+    constexpr int BM = WM * 64, BNt = WN * 32 * TN;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BNt - 1) / BNt;
     constexpr int NBUF = NS == 2 ? 2 : 1;
-    const size_t lds = (size_t)NBUF * NS * (BM + BNt) * ROW_B;
+    size_t lds = (size_t)NBUF * NS * (BM + BNt) * ROW_B;
+    // A grid that fits the chip in one round at one workgroup per CU should run that way: two 128x128 workgroups fit a
+    // CU's LDS, and the dispatcher does pair them up while other CUs stay empty (a workgroup alone on its CU ~29 us,
+    // sharing it ~45 us at K = 768).  Asking for more than half of the LDS keeps them apart.  E3D_GEMM_SPREAD=0: off.
+    static const bool spread = !getenv("E3D_GEMM_SPREAD") || atoi(getenv("E3D_GEMM_SPREAD")) != 0;
+    if (spread && BM * BNt == 128 * 128 && (int64_t)tiles_m * tiles_n <= e3d_cu_count() && lds < (size_t)84 * 1024) lds = (size_t)84 * 1024;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>, lds);
+    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>, (size_t)84 * 1024 > lds ? (size_t)84 * 1024 : lds);
     // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count; one round of
     // resident workgroups (more slices only add atomics: measured in round 1)
     int splits = 1;
@@ -881,7 +893,7 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
             return (int)e;
         }
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E>), dim3(tiles_m * tiles_n, splits),
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>), dim3(tiles_m * tiles_n, splits),
                        dim3(WM * WN * 64), lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk);
     return e3d_launch_status("e3d_gemm_f32_split");
 }

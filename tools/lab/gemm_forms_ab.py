@@ -15,7 +15,7 @@ ops, lib = pkg.ops, pkg.hip.lib()
 from e3diff_amd import autograd as AG  # noqa: E402
 
 DEV = "cuda:0"
-forms = [0, 1, 2]
+forms = [0, 1, 2, 3]
 
 
 def bench(fn):
