@@ -443,6 +443,9 @@ def main():
                             "sequence_B64_L128": bench_train.run("sequence", steps=5),
                             "note": "forward + loss + backward + grad-norm clip + fused AdamW, 12+12 / 6 layers x 768, "
                                     "synthetic batches, dropout 0 (the reference's 0.1 costs +0.7 ms)"}
+            import bench_single
+            # BASELINE configs[0] on the GPU: ONE 64-residue pocket, 50 reverse steps (latency, not throughput)
+            out["single_pocket"] = bench_single.run(seq_len=64, batch=1, steps=50)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, seed=0)
         print(json.dumps(out), flush=True)

@@ -23,17 +23,12 @@ from e3diff_amd.bert import BertConfig  # noqa: E402
 DEV = "cuda:0"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seq-len", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--graph", type=int, default=None, choices=(0, 1), help="1: replay one captured HIP graph per step, 0: eager launches (default: the sampler's own choice)")
-    a = ap.parse_args()
+def run(seq_len=64, batch=1, steps=50, graph=None, chains=3):
+    """Best of ``chains`` full reverse chains; returns a dict (also the ``single_pocket`` key of bench.py's line)."""
     from e3diff_amd.structure_model import sample as S
     from e3diff_amd.structure_model.model import ConditionalBertForDiffusionBase
     from e3diff_amd.structure_model.utils import CosineTables, modulo_with_wrapped_range
-    L, B, T = a.seq_len, a.batch, a.steps
+    L, B, T = seq_len, batch, steps
     c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=12, max_position_embeddings=L)
     torch.manual_seed(0)
     model = ConditionalBertForDiffusionBase(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), 8).eval().to(DEV)
@@ -43,19 +38,36 @@ def main():
 
     def chain():
         return S.p_sample_loop(model, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"],
-                               pk["receptor_angles"], T, tab, disable_pbar=True, return_device=True, step=1, use_graph=None if a.graph is None else bool(a.graph))
+                               pk["receptor_angles"], T, tab, disable_pbar=True, return_device=True, step=1,
+                               use_graph=None if graph is None else bool(graph))
 
-    chain()
-    torch.cuda.synchronize()
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
+    with pkg.ops.arithmetic(S.ARITHMETIC):
         chain()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    print(f"single-pocket sampling B={B} L={L} T={T} ({pkg.ops.GEMM_MODE}, skinny GEMM M<={pkg.ops.SKINNY_MAX_M}, "
-          f"graph={a.graph}): {best * 1e3:.1f} ms per chain = {best / T * 1e3:.3f} ms per reverse step (encoder cached)", flush=True)
+        best = None
+        for _ in range(chains):
+            t0 = time.perf_counter()
+            out = chain()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        mode = pkg.ops.GEMM_MODE
+    assert bool(torch.isfinite(out).all())
+    return {"batch": B, "seq_len": L, "timesteps": T, "arithmetic": mode, "graph_replay": "sampler default" if graph is None else bool(graph),
+            "ms_per_chain": best * 1e3, "ms_per_step": best / T * 1e3,
+            "note": "structure_model/sample.py p_sample_loop: encoder + cross K/V once per chain, 12-layer decoder + DDPM update per step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seq-len", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--graph", type=int, default=None, choices=(0, 1), help="1: replay one captured HIP graph per step, 0: eager launches (default: the sampler's own choice)")
+    a = ap.parse_args()
+    r = run(a.seq_len, a.batch, a.steps, a.graph)
+    print(f"single-pocket sampling B={r['batch']} L={r['seq_len']} T={r['timesteps']} ({r['arithmetic']}, skinny GEMM M<={pkg.ops.SKINNY_MAX_M}, "
+          f"graph={a.graph}): {r['ms_per_chain']:.1f} ms per chain = {r['ms_per_step']:.3f} ms per reverse step (encoder cached)", flush=True)
 
 
 if __name__ == "__main__":

@@ -64,10 +64,11 @@ dump(gw, f"{tag}_gemm_act0_bench_step_pmc_write.csv")
 shutil.copy(f"{O}/stats/bench_kernel_stats.csv", os.path.join(P, f"{tag}_bench_B256_L256_kernel_stats.csv"))
 for sub, name in (("stats_attn/attn_kernel_stats.csv", "attn_relkey_L64_L128_L256_kernel_stats.csv"),
                   ("stats_train_structure/t_kernel_stats.csv", "train_structure_B32_L128_kernel_stats.csv"),
-                  ("stats_train_sequence/t_kernel_stats.csv", "train_sequence_B64_L128_kernel_stats.csv")):
+                  ("stats_train_sequence/t_kernel_stats.csv", "train_sequence_B64_L128_kernel_stats.csv"),
+                  ("stats_single/s_kernel_stats.csv", "single_pocket_L64_T50_kernel_stats.csv")):
     if os.path.exists(f"{O}/{sub}"):
         shutil.copy(f"{O}/{sub}", os.path.join(P, f"{tag}_{name}"))
-for log in ("attn_shapes.log", "train_structure.log", "train_sequence.log"):
+for log in ("attn_shapes.log", "train_structure.log", "train_sequence.log", "single_pocket.log"):
     if os.path.exists(f"{O}/{log}"):
         shutil.copy(f"{O}/{log}", os.path.join(P, f"{tag}_{log}"))
 line = [ln for ln in open(f"{O}/bench_under_rocprof.log") if ln.startswith("{")][-1]

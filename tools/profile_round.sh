@@ -19,4 +19,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_attn -o attn --
 # training steps (BASELINE configs 2 and 4, one GPU's share)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_structure -o t -- python3 $R/tools/bench_train.py structure --steps 5 > $O/train_structure.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train_sequence -o t -- python3 $R/tools/bench_train.py sequence --steps 5 > $O/train_sequence.log 2>&1
+# ONE 64-residue pocket, 50 reverse steps (BASELINE configs[0] on the GPU): graph replay of the small-M kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_single -o s -- python3 $R/tools/bench_single.py > $O/single_pocket.log 2>&1
 find $O -name "*stats.csv" | head -20
