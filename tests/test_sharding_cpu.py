@@ -65,6 +65,20 @@ def _worker(rank, world, port, q):
     assert model["unused"].weight.grad is None
     views = [p.grad.untyped_storage().data_ptr() for p in model.parameters() if p.grad is not None]
     assert len(set(views)) <= len(avg.buckets)       # every grad lives inside a bucket buffer
+    # ---- gradients written OUTSIDE autograd's accumulation (autograd.deferred_weight_grads computes the weight gradients
+    # of the linear layers after backward and adds them into the bucket views): no hook fires, the writer reports them
+    for p in model.parameters():
+        p.grad = None
+    avg.prepare()
+    used = [p for n, p in model.named_parameters() if not n.startswith("unused.")]
+    for p, g in zip(used, [both[rank]] + [torch.full_like(p, float(rank + 1)) for p in used[1:]]):
+        assert float(p.grad.abs().max()) == 0.0           # zeroed view of its bucket
+        p.grad.add_(g)                                    # what the grouped launch does (accumulate bit set)
+        avg.mark_ready(p)
+    avg.average()
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
+    assert torch.allclose(model["b"].bias.grad, torch.full_like(model["b"].bias, 1.5))
+    assert model["unused"].weight.grad is None
     w0 = [torch.zeros_like(model["a"].weight) for _ in range(world)]
     torch.distributed.all_gather(w0, model["a"].weight.data)
     assert torch.equal(w0[0], w0[1])

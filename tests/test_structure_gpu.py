@@ -140,6 +140,28 @@ def test_cached_receptor_path_is_identical(pkg, hip):
     assert torch.equal(a, b)
 
 
+def test_timestep_modulation_rows_match_the_per_step_path(pkg, hip):
+    """The samplers hoist what depends on the timestep alone (Fourier features -> adaLN modulation) out of the loop:
+    ``decode(mod=row)`` against ``decode`` computing it itself -- one shared [1,6H] row, per-item rows, and a row of
+    the table p_sample_loop builds for a whole chain (a batched GEMM: other summation order, fp32 rounding apart)."""
+    cfg = dict(FULL_STRUCT, num_hidden_layers=2)
+    model, _ = build(pkg, cfg, 64, seed=5)
+    with torch.no_grad():                                   # the modulation MLP is zero-initialised (model.py:50-51)
+        model.timestep_emb.adaLN_modulation[0].weight.normal_(0, 0.05)
+        model.timestep_emb.adaLN_modulation[0].bias.normal_(0, 0.05)
+    d = to_dev(synthetic_pockets(3, 64, seed=9))
+    x_t = torch.randn(3, 64, 8, device=DEV)
+    rec = model.encode_receptor(d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
+    t = torch.full((3,), 977, device=DEV)
+    want = model.decode(t, x_t, d["ligand_attn_mask"], rec)
+    per_item = model.timestep_modulation(t)                                     # [3,6H]
+    assert torch.equal(model.decode(t, x_t, d["ligand_attn_mask"], rec, mod=per_item), want)
+    assert rel_err(model.decode(t, x_t, d["ligand_attn_mask"], rec, mod=per_item[:1].contiguous()), want) < 1e-6
+    table = model.timestep_modulation(torch.arange(1000, device=DEV))          # the chain's table: M = 1000 rows
+    assert rel_err(table[977:978], per_item[:1]) < 2e-6
+    assert rel_err(model.decode(t, x_t, d["ligand_attn_mask"], rec, mod=table[977:978]), want) < 2e-6
+
+
 def test_sampling_loop_matches_oracle_and_properties(pkg, hip):
     from e3diff_amd.structure_model.sample import p_sample, p_sample_loop
     cfg = dict(FULL_STRUCT, num_hidden_layers=2)
