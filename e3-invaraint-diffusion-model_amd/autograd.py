@@ -5,6 +5,8 @@ fused forward kernel has a hand-written backward kernel behind the same C-ABI).
 ``functional.*`` entry points pick the plain inference op when no gradient is required, so the
 sampling path pays nothing for the training support.
 """
+import os
+
 import torch
 
 from . import hip, ops
@@ -54,7 +56,7 @@ class deferred_weight_grads:
     def add(self, dz, x, weight, bias):
         self.pending.append((dz, x, weight, bias))
 
-    MIN_TILES = 192      # 256x128 output tiles a grouped launch needs (of 256 CUs)
+    MIN_TILES = int(os.environ.get("E3D_WGRAD_MIN_TILES", "96"))   # 256x128 output tiles a grouped launch needs (of 256 CUs; sweep in DESIGN.md)
 
     @staticmethod
     def _single(dz, x, w, b, N, K, M):

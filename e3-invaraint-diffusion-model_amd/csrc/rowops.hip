@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256) void embed_layernorm_kernel(
         for (int f = 0; f < F; ++f) {
             const float xv = xr[f];
 #pragma unroll
-            for (int i = 0; i < V; ++i) r[i] += xv * *reinterpret_cast<const f32x4*>(wt + f * H + 4 * (64 * i + lane));
+            for (int i = 0; i < V; ++i) {   // explicit fma: the per-row kernel below must round the same way
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wt + f * H + 4 * (64 * i + lane));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i][j] = __builtin_fmaf(xv, w[j], r[i][j]);
+            }
         }
         if (z_out) row_store<V>(r, z_out + (int64_t)row * H, lane);  // pre-LayerNorm rows for the backward
         row_normalize<V>(r, eps);
@@ -148,12 +152,26 @@ __global__ __launch_bounds__(256) void embed_layernorm_rows_kernel(
     row_load<V>(r, bias, lane);
     row_load<V>(g, gamma, lane);
     row_load<V>(b, beta, lane);
-    for (int f = 0; f < F; ++f) {
-        const float xv = xr[f];
+    if ((F & 3) == 0 && ((((uintptr_t)x | (uintptr_t)W) & 15) == 0)) {   // 16-byte loads of W (F = 8 angle features, 20 classes): same per-element order of the adds
+        for (int f0 = 0; f0 < F; f0 += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + f0);
 #pragma unroll
-        for (int i = 0; i < V; ++i)
+            for (int i = 0; i < V; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[i][j] += xv * W[(int64_t)(4 * (64 * i + lane) + j) * F + f];
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (int64_t)(4 * (64 * i + lane) + j) * F + f0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r[i][j] = __builtin_fmaf(xv[q], w[q], r[i][j]);
+                }
+        }
+    } else {
+        for (int f = 0; f < F; ++f) {
+            const float xv = xr[f];
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i][j] = __builtin_fmaf(xv, W[(int64_t)(4 * (64 * i + lane) + j) * F + f], r[i][j]);
+        }
     }
     if (z_out) row_store<V>(r, z_out + (int64_t)row * H, lane);
     row_normalize<V>(r, eps);

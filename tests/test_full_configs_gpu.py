@@ -171,6 +171,22 @@ def test_config2_structure_training_step_32x128_full_depth(pkg, hip, capsys):
     # error is amplified ~1000x there.  (The reference trains at torch's "medium" matmul precision -- bf16 products,
     # 2^-8 per product, structure_model/train_model.py:120 -- i.e. 500x coarser than bf16x3.)
     assert errs["global"] < GLOBAL_L2_TOL and max(errs["l2"].values()) < PARAM_L2_TOL and max(errs["max"].values()) < PARAM_MAX_TOL, errs["global"]
+    # (d) the step as training.fit runs it: weight / bias gradients of all linear layers computed at the end of the
+    # backward pass, grouped by shape (autograd.deferred_weight_grads) -- the same sums in another order (whole
+    # reductions instead of split-K atomics), so they agree with the layer-by-layer gradients far inside the
+    # arithmetic's own error; and the grouped launches really ran (12+12 layers: several groups of >= 192 tiles)
+    from e3diff_amd.autograd import deferred_weight_grads
+    with pkg.ops.arithmetic("bf16x3", respect_env=False):
+        model.zero_grad(set_to_none=True)
+        loss = model.training_step(db)
+        with deferred_weight_grads() as q:
+            loss.backward()
+            n_queued = len(q.pending)
+        grouped = grads_of(model)
+    assert n_queued > 200 and set(grouped) == set(grads["bf16x3"])
+    errs_g = grad_errors(grouped, grads["bf16x3"])
+    report_grad_errors("config 2, grouped weight gradients vs layer by layer (both bf16x3)", errs_g, capsys)
+    assert errs_g["global"] < 2e-6 and max(errs_g["l2"].values()) < 2e-5, errs_g["global"]
     optim = model.configure_optimizers()["optimizer"]
     torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 1.0)
     optim.step()
