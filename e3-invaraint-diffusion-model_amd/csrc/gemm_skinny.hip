@@ -266,7 +266,7 @@ int launch_partials(const float* A, int64_t lda, const float* W, const float* bi
 int check_common(const float* A, int64_t lda, const float* W, const float* out, int M, int N, int K, int terms,
                  const void* workspace, int64_t workspace_bytes) {
     E3D_REQUIRE(A && W && out && workspace, "gemm_skinny: null pointer");
-    E3D_REQUIRE(M > 0 && M <= 128 && N > 0 && K > 0, "gemm_skinny: needs 0 < M <= 128 (M=%d N=%d K=%d)", M, N, K);
+    E3D_REQUIRE(M > 0 && M <= 4096 && N > 0 && K > 0, "gemm_skinny: needs 0 < M <= 4096 (M=%d N=%d K=%d)", M, N, K);
     E3D_REQUIRE(N % 32 == 0 && K % 16 == 0 && lda % 4 == 0 && lda >= K,
                 "gemm_skinny: needs N%%32==0, K%%16==0, lda%%4==0 (N=%d K=%d lda=%lld)", N, K, (long long)lda);
     E3D_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)workspace % 16) == 0,

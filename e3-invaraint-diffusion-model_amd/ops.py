@@ -135,11 +135,15 @@ def set_gemm_mode(mode):
     return prev
 
 
-# Small-M launches (single-pocket / few-pocket sampling) go to the "skinny" kernels (csrc/gemm_skinny.hip: K cut across
+# Small launches (one to ~16 pockets per step) go to the "skinny" kernels (csrc/gemm_skinny.hip: K cut across
 # workgroups so the whole chip streams the weight, partial tiles in a workspace, a second launch finishes the rows).  The
 # workspace must not be shared by launches that may run concurrently: one per (device, stream), grown on demand and kept.
+# Where they win (tools/lab/skinny_ab.py, graph-timed, K = 768): up to ~768 output tiles of 32x32 -- M = 64: 7.4 us
+# against 21-28 us tiled, M = 256: 11 against 23.5, M = 512 x N = 768: 15.5 against 23.8, M = 1024 x N = 768: 21.5
+# against 24.2; beyond that the tiled kernels (a 24-step k chain, ~24 us) are faster (M = 512 x N = 2304: 33 vs 24.5).
 # E3D_GEMM_SKINNY=0 disables the path (A/B timing).
-SKINNY_MAX_M = 128 if os.environ.get("E3D_GEMM_SKINNY", "1") == "1" else 0
+SKINNY_MAX_M = 1024 if os.environ.get("E3D_GEMM_SKINNY", "1") == "1" else 0
+SKINNY_MAX_TILES = 768
 _SKINNY_WS = {}
 
 
@@ -154,7 +158,8 @@ def _skinny_workspace(device, M, N, K):
 
 
 def _skinny_ok(terms, M, N, K, a):
-    return terms in (3, 19) and 0 < M <= SKINNY_MAX_M and N % 32 == 0 and K % 16 == 0 and a.stride(0) % 4 == 0
+    return (terms in (3, 19) and 0 < M <= SKINNY_MAX_M and N % 32 == 0 and K % 16 == 0 and a.stride(0) % 4 == 0
+            and -(-M // 32) * (N // 32) <= SKINNY_MAX_TILES)
 
 
 def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):

@@ -117,7 +117,7 @@ class GraphedReverseStep:
     also the row of the [T,4] coefficient table read by ``e3d_ddpm_step_wrap_table``), the state
     ``self.x`` and the noise draw.  Results are bit-identical to the eager path for the same noise.
 
-    Default for chains of at most ops.SKINNY_MAX_M token rows (one or two pockets), ``use_graph=True`` /
+    Default for chains of at most GRAPH_MAX_ROWS token rows (up to ~16 pockets of 64 residues), ``use_graph=True`` /
     E3D_SAMPLE_GRAPH=1 forces it, =0 turns it off.  Measured on MI355X, one 64-residue pocket (tools/bench_single.py):
     round 1, 6-workgroup tiled GEMMs of ~29 us each: 3.9 ms per replayed step against 3.8 ms eager -- the GPU was 100 %
     busy with dependent kernels, the graph had nothing to remove.  Round 2, K-sliced small-M GEMMs of ~7 us per product
@@ -165,11 +165,14 @@ class GraphedReverseStep:
         return self.out
 
 
+GRAPH_MAX_ROWS = 512      # token rows (B x L) up to which a chain replays a captured graph by default (B=8 x L=64: 2.05 vs 2.16 ms eager; B=16: GPU-bound, eager)
+
+
 def _use_graph(x):
     env = os.environ.get("E3D_SAMPLE_GRAPH")
     if env in ("0", "1"):
         return env == "1"
-    return x.shape[0] * x.shape[1] <= ops.SKINNY_MAX_M
+    return x.shape[0] * x.shape[1] <= GRAPH_MAX_ROWS
 
 
 def trimmed_length(mask, multiple=32):

@@ -93,7 +93,8 @@ int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs,
                               float* out, float* lse, int B, int nh, int Lq, int Lk, int terms,
                               void* stream);
 
-/* The same product for M <= 128 rows (single-pocket / few-pocket sampling: BASELINE configs[0]), cut along K as well so
+/* The same product for small launches (one to ~16 pockets per step: BASELINE configs[0]; M <= 4096 accepted, the host mirror
+ * sends up to ~768 output tiles of 32x32 here, where it beats the tiled kernels), cut along K as well so
  * that the whole chip streams the weight: one wave per (32 rows, 32 columns, K slice) writes a partial tile into the
  * workspace, a second small launch sums the slices in slice order (deterministic) and applies bias and activation.
  * Two launches on the given stream.  terms = 3 (bf16x3) or 19 (f16x3).  N % 32 == 0, K % 16 == 0, lda % 4 == 0,

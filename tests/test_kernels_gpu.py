@@ -432,14 +432,14 @@ def test_f16x3_range_contract(pkg, hip):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 128, 32), (64, 768, 768), (64, 2304, 768), (33, 768, 1024), (128, 4608, 768),
-                                   (100, 1024, 3072), (64, 768, 48)])
+                                   (100, 1024, 3072), (64, 768, 48), (512, 768, 768), (1000, 768, 1024), (256, 2304, 768)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("f16x3", 5e-6)])
 def test_gemm_skinny_split_k(pkg, hip, M, N, K, act, mode, tol):
     """The small-M kernels (one wave per 32x32 tile and K slice, slices summed in slice order by a second launch):
     against fp64; run-to-run bit-identical; a strided activation view; rows past M; launches of different shapes share
     one workspace back to back (nothing of an earlier shape's slabs may show)."""
-    assert M <= pkg.ops.SKINNY_MAX_M
+    assert pkg.ops._skinny_ok(pkg.ops.GEMM_MODES[mode], M, N, K, torch.empty(1, K))   # the shape takes the skinny path
     wide = torch.randn(M, K + 32, generator=g(M + N))
     a = wide[:, 16:16 + K]
     w = torch.randn(N, K, generator=g(K)) / math.sqrt(K)
@@ -461,7 +461,8 @@ def test_gemm_skinny_split_k(pkg, hip, M, N, K, act, mode, tol):
         assert rel_err(outs[0], tiled) < 2e-6
 
 
-@pytest.mark.parametrize("M,H,K", [(64, 768, 768), (64, 768, 1024), (33, 256, 512), (128, 1024, 3072), (5, 512, 64)])
+@pytest.mark.parametrize("M,H,K", [(64, 768, 768), (64, 768, 1024), (33, 256, 512), (128, 1024, 3072), (5, 512, 64),
+                                   (512, 768, 1024), (1024, 768, 768)])
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 3e-5), ("f16x3", 5e-6)])
 def test_gemm_skinny_residual_layernorm(pkg, hip, M, H, K, mode, tol):
     """BertSelfOutput / BertOutput in one call (dense -> + residual -> LayerNorm): bit-identical to the unfused pair
@@ -479,7 +480,7 @@ def test_gemm_skinny_residual_layernorm(pkg, hip, M, H, K, mode, tol):
         assert torch.equal(fused, pair)
         assert rel_err(fused, ref) < 4 * tol
     # larger M: the same entry point falls back to the two ops
-    big = torch.randn(256, K, device=DEV)
+    big = torch.randn(2048, K, device=DEV)
     assert torch.equal(pkg.ops.linear_residual_layernorm(big, wd, bd, None, gd, be, 1e-12, mode=mode),
                        pkg.ops.residual_layernorm(pkg.ops.gemm(big, wd, bd, mode=mode), None, gd, be, 1e-12))
 

@@ -32,7 +32,7 @@ def graph_time(fn):
     return sorted(ts)[3]
 
 
-for M in (32, 64, 128):
+for M in (64, 128, 256, 512, 1024, 2048):
     for N, K, act in ((768, 768, 0), (2304, 768, 0), (1024, 768, 1), (768, 1024, 0), (1536, 768, 0)):
         # a ring of distinct weights (as in a model: every launch streams its own W from HBM)
         ws = [torch.randn(N, K, device=DEV) / K ** 0.5 for _ in range(8)]
@@ -46,8 +46,8 @@ for M in (32, 64, 128):
         res = {}
         ops.SKINNY_MAX_M = 0
         res["tiled"] = graph_time(fn)
-        ops.SKINNY_MAX_M = 128
-        for wx2, mk in ((6, 96), (4, 96), (3, 96), (8, 96), (6, 192), (4, 192)):
+        ops.SKINNY_MAX_M = 4096
+        for wx2, mk in ((3, 96), (6, 96), (3, 192), (3, 384)):
             lib.e3d_gemm_skinny_plan_select(wx2, mk)
             res[f"sk{wx2 / 2:g}/{mk}"] = graph_time(fn)
         lib.e3d_gemm_skinny_plan_select(0, 0)
