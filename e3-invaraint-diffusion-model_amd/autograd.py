@@ -36,11 +36,12 @@ class deferred_weight_grads:
     writes them straight into ``param.grad`` (added to an existing gradient, like autograd's accumulation).
     Nothing reaches autograd's own accumulation for these parameters, so post-accumulate-grad hooks do not fire for
     them: ``on_param`` (called per parameter at flush time, after its gradient is enqueued) is where a gradient
-    averager learns that the gradient is there (sharding.GradientAverager.mark_ready)."""
+    averager learns that the gradient is there (sharding.GradientAverager.mark_ready); the queue is then worked off in
+    ``stages`` slices, last layers first, so that the first buckets travel while the later slices compute."""
     active = None
 
-    def __init__(self, on_param=None):
-        self.pending, self.on_param = [], on_param
+    def __init__(self, on_param=None, stages=3):
+        self.pending, self.on_param, self.stages = [], on_param, max(1, int(stages))
 
     def __enter__(self):
         assert deferred_weight_grads.active is None, "deferred_weight_grads blocks do not nest"
@@ -79,8 +80,31 @@ class deferred_weight_grads:
         return p.grad, True
 
     def flush(self):
-        import ctypes
         pending, self.pending = self.pending, []
+        if not pending:
+            return
+        # With a gradient averager listening (on_param), the queue is worked off in ``stages`` slices, last layers
+        # first (the order backward queued them = the order of the averager's buckets): a slice's parameters are
+        # reported as soon as its launches are enqueued, so their buckets go on the wire while the next slice computes.
+        # Alone (one process) one slice: the largest groups.
+        stages = self.stages if self.on_param is not None else 1
+        per = -(-len(pending) // stages)
+        slices = [pending[i:i + per] for i in range(0, len(pending), per)]
+        last_slice = {}
+        for si, sl in enumerate(slices):
+            for _, _, w, b in sl:
+                last_slice[id(w)] = si
+                if b is not None:
+                    last_slice[id(b)] = si
+        for si, sl in enumerate(slices):
+            touched = self._flush_slice(sl)
+            if self.on_param is not None:
+                for p in touched.values():       # once per parameter, after its last use
+                    if last_slice[id(p)] == si:
+                        self.on_param(p)
+
+    def _flush_slice(self, pending):
+        import ctypes
         terms = ops.GEMM_MODES[ops.GEMM_MODE] or 6
         lib = hip.lib()
         # a weight used more than once in the forward pass: its later uses go to later rounds (a launch must not
@@ -126,9 +150,7 @@ class deferred_weight_grads:
                         touched[id(w)] = w
                         if has_bias:
                             touched[id(b)] = b
-        if self.on_param is not None:
-            for p in touched.values():       # once per parameter, whatever the number of uses
-                self.on_param(p)
+        return touched
 
 
 def colsum(x):

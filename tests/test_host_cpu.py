@@ -312,3 +312,34 @@ def test_weight_caches_follow_fused_optimizer_steps(pkg):
         pack1 = bert.qkv_weights(att)[0]
     assert pack1 is not pack0 and torch.equal(pack1[:256], att.query.weight.detach())
     print("fused AdamW bumps _version:", fused_bumps_version)
+
+
+def test_deferred_weight_gradient_queue_reports_parameters_in_stages(pkg):
+    """autograd.deferred_weight_grads with a gradient averager listening: the queue (backward order = last layers first)
+    is flushed in slices and every parameter is reported once, after the slice of its LAST use (host logic only: the
+    launches themselves are replaced by a recorder; the kernels are covered by tests/test_backward_gpu.py)."""
+    from e3diff_amd.autograd import deferred_weight_grads
+    ws = [torch.nn.Parameter(torch.zeros(2, 2)) for _ in range(7)]
+    index = {id(w): i for i, w in enumerate(ws)}
+    calls = []
+    q = deferred_weight_grads(on_param=lambda p: calls.append(("ready", index[id(p)])), stages=3)
+
+    def fake_slice(items):
+        calls.append(("slice", [index[id(it[2])] for it in items]))
+        return {id(it[2]): it[2] for it in items}
+
+    q._flush_slice = fake_slice
+    for i in (6, 5, 4, 3, 2, 1, 0, 6):      # weight 6 is used twice (first and last in backward order)
+        q.add(None, None, ws[i], None)
+    q.flush()
+    assert calls == [("slice", [6, 5, 4]), ("ready", 5), ("ready", 4), ("slice", [3, 2, 1]), ("ready", 3), ("ready", 2),
+                     ("ready", 1), ("slice", [0, 6]), ("ready", 0), ("ready", 6)]
+    assert q.pending == []
+    # nobody listening: one slice (the largest groups)
+    calls.clear()
+    q2 = deferred_weight_grads()
+    q2._flush_slice = fake_slice
+    for i in (2, 1, 0):
+        q2.add(None, None, ws[i], None)
+    q2.flush()
+    assert calls == [("slice", [2, 1, 0])]
