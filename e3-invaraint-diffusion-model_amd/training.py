@@ -93,7 +93,7 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             # the weight gradients of all linear layers are computed together when the block ends (grouped launches,
             # written into .grad, i.e. into the all-reduce buckets); E3D_DEFER_WGRAD=0: layer by layer inside backward
             if DEFER_WEIGHT_GRADS:
-                with autograd.deferred_weight_grads(on_param=averager.mark_ready):
+                with autograd.deferred_weight_grads(on_param=averager.mark_ready if averager._active() else None):
                     loss.backward()
             else:
                 loss.backward()

@@ -227,9 +227,16 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
     model.zero_grad(set_to_none=True)
     if defer:
         from e3diff_amd.autograd import deferred_weight_grads
-        with deferred_weight_grads() as q:
+        reported = []
+        staged = defer == "staged"         # as under a gradient averager: flushed in 3 slices, parameters reported
+        with deferred_weight_grads(on_param=reported.append if staged else None, stages=3) as q:
             loss_dev.backward()
-            assert len(q.pending) > 10     # the linear layers really took the deferred path
+            n_queued = len(q.pending)
+            assert n_queued > 10           # the linear layers really took the deferred path
+        if staged:
+            ids = [id(p) for p in reported]
+            assert len(ids) == len(set(ids)) and len(ids) >= n_queued   # weights + biases, each exactly once
+            assert all(p.grad is not None for p in reported)
     else:
         loss_dev.backward()
     ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -256,7 +263,7 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
     return max(worst.values())
 
 
-@pytest.mark.parametrize("defer", [False, True])
+@pytest.mark.parametrize("defer", [False, True, "staged"])
 @pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4)])   # measured on MI355X: 4.0e-6 / 4.1e-5
 def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, defer, capsys):
     """Whole structure model, loss of the reference (wrapped L1 x4 + smooth-L1 x4), every parameter
@@ -294,7 +301,7 @@ def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, def
         print(f"\n[structure grads, {mode}{', grouped weight gradients' if defer else ''}] worst relative gradient error {worst:.2e}")
 
 
-@pytest.mark.parametrize("defer", [False, True])    # True: incl. ligand_feature_emb, whose weights are used twice
+@pytest.mark.parametrize("defer", [False, True, "staged"])    # deferred: incl. ligand_feature_emb, whose weights are used twice
 def test_sequence_training_step_gradients_match_oracle(pkg, hip, defer, capsys):
     from e3diff_amd.bert import BertConfig
     from e3diff_amd.sequence_model.model import PeptideDiff
