@@ -165,6 +165,56 @@ __global__ __launch_bounds__(256) void adaln_gate_bwd_kernel(const float* __rest
     }
 }
 
+// The same for conditioning rows shared by rows_per_cond % 16 == 0 consecutive rows (one timestep row per item): a
+// workgroup takes 16 rows of ONE conditioning row (4 per wave), sums the three modulation gradients in registers, then
+// over its waves in LDS, and adds them once -- 1/16 of the float atomics of the per-row form (88 -> ~25 us at
+// 4096 x 768: 9.4 M atomics onto 32 x 2304 addresses were the kernel).
+template <int V>
+__global__ __launch_bounds__(256) void adaln_gate_bwd_shared_kernel(const float* __restrict__ dout,
+                                                                    const float* __restrict__ y,
+                                                                    const float* __restrict__ mod, int branch,
+                                                                    int rows_per_cond, float* __restrict__ dy,
+                                                                    float* __restrict__ dmod, int M) {
+    constexpr int H = 256 * V;
+    __shared__ float red[4][3][H];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 16;
+    const int64_t moff = (int64_t)(row0 / rows_per_cond) * 6 * H + (int64_t)branch * 3 * H;
+    f32x4 sh[V], sc[V], ga[V], a_sh[V], a_sc[V], a_ga[V];
+    row_load<V>(sh, mod + moff, lane);
+    row_load<V>(sc, mod + moff + H, lane);
+    row_load<V>(ga, mod + moff + 2 * H, lane);
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a_sh[i] = 0.f; a_sc[i] = 0.f; a_ga[i] = 0.f; }
+#pragma unroll 2
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + 4 * r + w;
+        if (row >= M) break;
+        f32x4 yh[V], go[V];
+        row_load<V>(yh, y + (int64_t)row * H, lane);
+        row_load<V>(go, dout + (int64_t)row * H, lane);
+        const float rstd = row_normalize<V>(yh, 1e-5f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            a_ga[i] += go[i] * (yh[i] * (1.0f + sc[i]) + sh[i]);
+            const f32x4 dsh = go[i] * ga[i];
+            a_sh[i] += dsh;
+            a_sc[i] += dsh * yh[i];
+            go[i] = dsh * (1.0f + sc[i]);  // d(yhat)
+        }
+        ln_input_grad<V>(go, yh, rstd);
+        row_store<V>(go, dy + (int64_t)row * H, lane);
+    }
+    row_store<V>(a_sh, red[w][0], lane);
+    row_store<V>(a_sc, red[w][1], lane);
+    row_store<V>(a_ga, red[w][2], lane);
+    __syncthreads();
+    for (int c = threadIdx.x; c < 3 * H; c += 256) {
+        const int which = c / H, col = c - which * H;
+        atomicAdd(dmod + moff + (int64_t)which * H + col, red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col]);
+    }
+}
+
 // ---------------------------------------------------------------- activations on saved z
 __device__ __forceinline__ float act_apply(float z, int act) {
     return act == E3D_ACT_GELU ? gelu_erf(z) : (act == E3D_ACT_SILU ? silu(z) : z);
@@ -295,6 +345,11 @@ extern "C" int e3d_adaln_gate_bwd(const float* dout, const float* y, const float
     E3D_REQUIRE(dout && y && mod && dy && dmod && M > 0, "adaln_gate_bwd: bad arguments");
     E3D_REQUIRE((branch == 0 || branch == 1) && rows_per_cond >= 1, "adaln_gate_bwd: branch=%d rows_per_cond=%d", branch,
                 rows_per_cond);
+    if (rows_per_cond % 16 == 0) {
+        DISPATCH_V(H, hipLaunchKernelGGL(adaln_gate_bwd_shared_kernel<V>, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream,
+                                         dout, y, mod, branch, rows_per_cond, dy, dmod, M));
+        return e3d_launch_status("e3d_adaln_gate_bwd");
+    }
     DISPATCH_V(H, hipLaunchKernelGGL(adaln_gate_bwd_kernel<V>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout,
                                      y, mod, branch, rows_per_cond, dy, dmod, M));
     return e3d_launch_status("e3d_adaln_gate_bwd");

@@ -103,7 +103,7 @@ def test_gemm_general_odd_reduction_and_strided(pkg, hip):
     assert rel_err(got, (a.t().double() @ b[:, 50:250].double()).float()) < 1e-5
 
 
-@pytest.mark.parametrize("H,M", [(768, 70), (256, 9), (1024, 33)])
+@pytest.mark.parametrize("H,M", [(768, 70), (256, 9), (1024, 33), (768, 96), (512, 160)])
 def test_layernorm_and_adaln_backward(pkg, hip, Fm, H, M):
     x, r = torch.randn(M, H, generator=g(1)) * 2, torch.randn(M, H, generator=g(2))
     ga, be = 1 + 0.1 * torch.randn(H, generator=g(3)), torch.randn(H, generator=g(4))
@@ -120,8 +120,9 @@ def test_layernorm_and_adaln_backward(pkg, hip, Fm, H, M):
     xr2 = leaf(x, dtype=torch.double)
     TF.layer_norm(xr2, (H,), ga.double(), be.double(), 1e-12).backward(go.double())
     assert rel_err(xd2.grad, xr2.grad.float()) < 1e-5
-    # adaLN gate, both broadcast modes and both branches
-    for rpc in (1, M):
+    # adaLN gate, both broadcast modes and both branches (M % 32 == 0: also two conditioning rows of M/2 rows each --
+    # multiples of 16 take the kernel that sums the modulation gradients per workgroup before its atomics)
+    for rpc in (1, M) + ((M // 2,) if M % 32 == 0 else ()):
         for branch in (0, 1):
             y = torch.randn(M, H, generator=g(6)) * 2
             mod = torch.randn(M // rpc, 6 * H, generator=g(7))
