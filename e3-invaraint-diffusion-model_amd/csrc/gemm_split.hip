@@ -44,6 +44,9 @@ __device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x
 }
 
 constexpr int BN = 128, BK = 32;
+#ifndef E3D_GEMM_FRAG_PREFETCH
+#define E3D_GEMM_FRAG_PREFETCH 1
+#endif
 // LDS rows are 64 bytes (32 bf16) unpadded, with the 16-byte k-chunk XOR-swizzled by (row >> 2) & 3: the 16 lanes
 // of a ds_read_b128 group (4 row quads) then hit 16 distinct 4-bank slots.
 constexpr int ROW_B = 64;
@@ -239,6 +242,21 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
         unsigned char* nxt = smem_raw + (cur ^ 1) * BUF_BYTES;
         const unsigned char* ab = smem_raw + cur * BUF_BYTES;
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES;
+        // form 3 (64x32 per wave: 6 fragment reads per 6 MFMAs and k16 block): the fragments of BOTH k16 blocks are
+        // read before the first MFMA, so the second block's LDS latency hides under the first block's MFMAs
+        constexpr bool PREF = PIPE && TN == 1 && E3D_GEMM_FRAG_PREFETCH;
+        typename Vec<E>::x8 fa2[2][NS][2], fb2[2][NS][TN];
+#pragma unroll
+        for (int ks = 0; ks < (PREF ? 2 : 0); ++ks)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    fa2[ks][s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    fb2[ks][s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
+            }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename Vec<E>::x8 fa[NS][2], fb[NS][TN];
@@ -246,10 +264,12 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
+                    fa[s][m] = PREF ? fa2[ks][s][m]
+                                    : *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
-                    fb[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
+                    fb[s][n] = PREF ? fb2[ks][s][n]
+                                    : *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
