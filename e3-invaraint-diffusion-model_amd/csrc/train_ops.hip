@@ -349,6 +349,33 @@ int elementwise_blocks(int64_t n) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// ---------------------------------------------------------------- grouped transposes (W^T of many weights at once)
+struct TransposeGroup {
+    const float* src[64];
+    float* dst[64];
+};
+
+// dst_p[c * ld_dst + r] = src_p[r * ld_src + c] for up to 64 matrices of one shape: 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_grouped_kernel(const TransposeGroup g, int rows, int cols, int64_t ld_src,
+                                                                int64_t ld_dst, int tiles_c) {
+    __shared__ float tile[32][33];
+    const float* __restrict__ src = g.src[blockIdx.y];
+    float* __restrict__ dst = g.dst[blockIdx.y];
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int y = y0; y < 32; y += 8) {
+        const int r = tr * 32 + y, c = tc * 32 + x;
+        if (r < rows && c < cols) tile[y][x] = src[(int64_t)r * ld_src + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int y = y0; y < 32; y += 8) {
+        const int c = tc * 32 + y, r = tr * 32 + x;
+        if (r < rows && c < cols) dst[(int64_t)c * ld_dst + r] = tile[x][y];
+    }
+}
+
 }  // namespace
 
 extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* gamma, float eps, float* ds,
@@ -402,6 +429,24 @@ extern "C" int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, 
     rpb = rpb < 16 ? 16 : rpb;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, s, x, ld, out, M, N, rpb);
     return e3d_launch_status("e3d_colsum");
+}
+
+extern "C" int e3d_transpose_grouped_f32(const float* const* src, float* const* dst, int count, int rows, int cols,
+                                        int64_t ld_src, int64_t ld_dst, void* stream) {
+    E3D_REQUIRE(src && dst && count >= 1 && count <= 64, "transpose_grouped: 1..64 matrices (count=%d)", count);
+    E3D_REQUIRE(rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "transpose_grouped: bad shape %d x %d (ld %lld / %lld)",
+                rows, cols, (long long)ld_src, (long long)ld_dst);
+    TransposeGroup g;
+    for (int p = 0; p < 64; ++p) {
+        const int q = p < count ? p : 0;
+        E3D_REQUIRE(src[q] && dst[q], "transpose_grouped: null pointer in matrix %d", q);
+        g.src[p] = src[q];
+        g.dst[p] = dst[q];
+    }
+    const int tiles_r = (rows + 31) / 32, tiles_c = (cols + 31) / 32;
+    hipLaunchKernelGGL(transpose_grouped_kernel, dim3(tiles_r * tiles_c, count), dim3(256), 0, (hipStream_t)stream, g, rows, cols,
+                       ld_src, ld_dst, tiles_c);
+    return e3d_launch_status("e3d_transpose_grouped_f32");
 }
 
 extern "C" int e3d_group_sum(const float* x, int rows_per_group, float* out, int M, int H, void* stream) {

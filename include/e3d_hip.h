@@ -325,6 +325,12 @@ int e3d_act_bwd(const float* dh, const float* z, int act, float* dz, int64_t n, 
 
 /* out[n] = sum_m x[m,n] (bias gradients);  out[g,:] = sum of rows_per_group consecutive rows. */
 int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, void* stream);
+/* Up to 64 matrices of one shape transposed in one launch: dst_p[c * ld_dst + r] = src_p[r * ld_src + c], r < rows,
+ * c < cols.  src, dst: HOST arrays of ``count`` device pointers.  (Training: W^T of every weight once per optimizer
+ * step, for the input-gradient GEMM dz . W in the forward layout -- one launch per weight shape instead of one copy
+ * kernel per layer; ld_dst lets the transposes of query / key / value land side by side as the W^T of the packed QKV.) */
+int e3d_transpose_grouped_f32(const float* const* src, float* const* dst, int count, int rows, int cols, int64_t ld_src,
+                              int64_t ld_dst, void* stream);
 int e3d_group_sum(const float* x, int rows_per_group, float* out, int M, int H, void* stream);
 
 /* dW[h,f] (transpose_out: [f,h]) = sum_m g[m,h] x[m,f], db[h] = sum_m g[m,h]; F <= 32

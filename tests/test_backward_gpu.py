@@ -338,3 +338,33 @@ def test_sequence_training_step_gradients_match_oracle(pkg, hip, defer, capsys):
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("receptor_feature_emb."))
     with capsys.disabled():
         print(f"\n[sequence grads, bf16x6] worst relative gradient error {worst:.2e}")
+
+
+def test_transposed_weight_registry_refreshes_all_stale_weights_together(pkg, hip):
+    """autograd._transposed_weight: weights (and packed query / key / value weights through their parts) are registered
+    on first use; after an optimizer step the first request re-transposes EVERY registered weight (grouped launches),
+    the others then hit the cache; values always equal W^T."""
+    from e3diff_amd import autograd as AG, ops
+    ws = [torch.nn.Parameter(torch.randn(n, k, generator=g(i)).to(DEV)) for i, (n, k) in
+          enumerate([(768, 256), (768, 256), (100, 70), (768, 256), (96, 1024)])]
+    q, k_, v = (torch.nn.Parameter(torch.randn(128, 64, generator=g(20 + i)).to(DEV)) for i in range(3))
+    packed = torch.cat([q, k_, v], 0)
+    packed._e3d_parts = [q, k_, v]
+    got = [AG._transposed_weight(w) for w in ws] + [AG._transposed_weight(packed)]
+    for w, t in zip(ws + [packed], got):
+        assert torch.equal(t, w.detach().t())
+    assert all(AG._transposed_weight(w) is t for w, t in zip(ws, got))          # cached
+    with torch.no_grad():
+        for p in ws + [q, k_, v]:
+            p.mul_(1.5)                                                         # in-place update: version bump
+    ops.invalidate_weight_caches()
+    first = AG._transposed_weight(ws[2])                                        # one request ...
+    assert first is got[2] and torch.equal(first, ws[2].detach().t())
+    keys_now = {id(w): AG._WT_REGISTRY[(id(w),)].key for w in ws}
+    assert all(keys_now[id(w)] == ops.weight_key(w) for w in ws)                # ... refreshed them all
+    packed2 = torch.cat([q, k_, v], 0)                                          # a new packed tensor every step
+    packed2._e3d_parts = [q, k_, v]
+    t2 = AG._transposed_weight(packed2)
+    assert t2 is got[-1] and torch.equal(t2, packed2.detach().t())
+    for w, t in zip(ws, got):
+        assert torch.equal(AG._transposed_weight(w), w.detach().t())

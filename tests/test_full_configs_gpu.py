@@ -220,7 +220,7 @@ def test_config2_m4096_gradients_match_oracle_and_wt_cache_survives_optimizer_st
             print(f"\n[config 2 shapes, M=4096, 2+2 layers, {mode}] worst per-parameter gradient error vs oracle {worst:.2e}")
         # ---- W^T cache across an optimizer step
         w = model.decoder.layer[0].output.dense.weight      # [768, 1024]: dx = dz . W through the cached W^T
-        wt_before = AG._transposed_weight(w)
+        wt_before = AG._transposed_weight(w).clone()        # (the cached buffer is refreshed in place)
         assert torch.equal(wt_before, w.detach().t())
         optim = model.configure_optimizers()["optimizer"]
         optim.step()                                    # in-place update: bumps w._version
