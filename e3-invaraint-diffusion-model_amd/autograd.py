@@ -181,8 +181,10 @@ def act_bwd(dh, z, act):
 def layernorm_bwd(dy, s, gamma, eps, want_affine_grads=True):
     M, H = s.shape
     ds = torch.empty_like(s)
-    dg = torch.empty((H,), device=s.device, dtype=torch.float32) if want_affine_grads else None
-    db = torch.empty((H,), device=s.device, dtype=torch.float32) if want_affine_grads else None
+    dg = db = None
+    if want_affine_grads:      # one allocation: the C side then zeroes both with one memset
+        both = torch.empty((2, H), device=s.device, dtype=torch.float32)
+        dg, db = both[0], both[1]
     hip.check(hip.lib().e3d_layernorm_bwd(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dg), _p(db), M, H, _stream()),
               "e3d_layernorm_bwd")
     return ds, dg, db

@@ -382,8 +382,12 @@ extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* g
                                  float* dgamma, float* dbeta, int M, int H, void* stream) {
     E3D_REQUIRE(dy && s && ds && M > 0, "layernorm_bwd: bad arguments");
     hipError_t e = hipSuccess;
-    if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
-    if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+    if (dgamma && dbeta == dgamma + H) {   // one buffer (autograd.layernorm_bwd allocates them so): one memset
+        e = hipMemsetAsync(dgamma, 0, (size_t)2 * H * sizeof(float), (hipStream_t)stream);
+    } else {
+        if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+        if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+    }
     E3D_REQUIRE(e == hipSuccess, "layernorm_bwd: memset failed: %s", hipGetErrorString(e));
     const int blocks = (M + 15) / 16 < 512 ? (M + 15) / 16 : 512;
     DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s,
