@@ -714,6 +714,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 #pragma unroll
     for (int n = 0; n < 2; ++n) b_row[n] = wc * 64 + n * 32 + l31;
     int cur = 0;
+#ifdef E3D_LAB_SETPRIO_STATIC
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
 
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         f32x16 acc[4][2];
@@ -745,12 +748,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                     const int g = ks * 4 + m;   // MFMA group g stages item g: stream k-tile +1 out, +2 in
                     item_store(g, next);
                     item_load(g);
+#ifdef E3D_LAB_SETPRIO
+                    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
                         acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                     }
+#ifdef E3D_LAB_SETPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
