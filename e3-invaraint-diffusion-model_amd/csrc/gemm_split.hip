@@ -656,7 +656,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
     for (int i = 0; i < NI; ++i) {
         const int f = tid + 512 * (i & 3), r = f >> 3, kg = f & 7;
         goff[i] = (unsigned)(r * (i < 4 ? (int)lda : K) + kg * 4);
+#ifdef E3D_LAB_PLANES
+        // lab (tools/lab/gemm_planes_ab.py): both operands arrive PRE-SPLIT -- per row and k-tile of 32, 32 hi terms then
+        // 32 lo terms (the same 128 bytes as 32 floats) -- so an item is 8 terms of one plane and goes to LDS as it is
+        dst[i] = (i < 4 ? 0 : NS * T_BYTES) + (kg >> 2) * T_BYTES + swz_off(r, kg & 3);
+#else
         dst[i] = (i < 4 ? 0 : NS * T_BYTES) + swz_off(r, kg >> 1) + (kg & 1) * 8;
+#endif
     }
 
     // load cursor: the k-tile the next global loads fetch (wave-uniform)
@@ -691,10 +697,14 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 #ifdef E3D_LAB_NO_STAGE
         if (K > 0) return;
 #endif
+#ifdef E3D_LAB_PLANES
+        *reinterpret_cast<f32x4*>(buf + dst[i]) = rg[i];
+#else
         typename Vec<E>::x4 p[NS];
         split4<NS, E>(rg[i], p);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(buf + s * T_BYTES + dst[i]) = p[s];
+#endif
     };
 
     cursor_bases();
