@@ -16,7 +16,9 @@ ops = pkg.ops
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 bad = 0
-for (M, N, K) in ((65536, 768, 768), (65536, 2304, 768), (32768, 1024, 1024), (16640, 1024, 768), (4096, 2304, 768), (8192, 768, 3072)):
+for (M, N, K) in ((65536, 768, 768), (65536, 2304, 768), (32768, 1024, 1024), (16640, 1024, 768), (4096, 2304, 768), (8192, 768, 3072),
+                  (4096, 768, 768), (2048, 768, 1024),                      # round 2: 8-wave 128x128 form
+                  (64, 768, 768), (512, 768, 1024), (256, 2304, 768)):     # round 2: K-sliced small-launch kernels
     worst = 0.0
     for r in range(reps):
         g = torch.Generator(device=dev).manual_seed(1000 * r + M % 977)
