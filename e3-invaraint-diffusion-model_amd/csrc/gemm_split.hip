@@ -652,6 +652,20 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 
     unsigned goff[NI];   // element offset from the tile base
     int dst[NI];
+#ifdef E3D_LAB_PLANES_GLDS
+    // lab: both operands pre-split (the E3D_LAB_PLANES layout) and staged by LDS-DMA (global_load_lds, 16 bytes per lane,
+    // lane-linear LDS image: the swizzle is applied to the SOURCE position).  Wave w moves pieces 8w .. 8w+7 of a k-tile
+    // buffer; piece = 1 KB = 16 rows of one plane.  No staging registers, no split, no ds_write.
+    bool piece_is_a[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int piece = wid * 8 + i, plane = piece >> 4, row = (piece & 15) * 16 + (lane >> 2), slot = lane & 3;
+        const int chunk = slot ^ ((row >> 2) & 3);
+        piece_is_a[i] = plane < 2;
+        goff[i] = (unsigned)(row * (plane < 2 ? (int)lda : K) + (plane & 1) * 16 + chunk * 4);
+        dst[i] = __builtin_amdgcn_readfirstlane(plane * T_BYTES + (piece & 15) * 1024);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int f = tid + 512 * (i & 3), r = f >> 3, kg = f & 7;
@@ -664,6 +678,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
         dst[i] = (i < 4 ? 0 : NS * T_BYTES) + swz_off(r, kg >> 1) + (kg & 1) * 8;
 #endif
     }
+#endif
 
     // load cursor: the k-tile the next global loads fetch (wave-uniform)
     int ld_tile = blockIdx.x, ld_k = 0;
@@ -692,8 +707,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
     // -DE3D_LAB_* (tools/lab/build_variant.sh, timing only -- results are wrong): ablations that price the parts of
     // this kernel: FIXED_OPERANDS = every k-tile re-reads the stream's first one (memory path off), NO_STAGE = no
     // split + LDS writes, NO_STORE = no output stores
-    auto item_load = [&](int i) { rg[i] = *reinterpret_cast<const f32x4*>((i < 4 ? ld_a : ld_w) + goff[i]); };
+#ifdef E3D_LAB_PLANES_GLDS
+    auto item_load = [&](int) {};
     auto item_store = [&](int i, unsigned char* buf) {
+        const float* g = (piece_is_a[i] ? ld_a : ld_w) + goff[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(buf + dst[i]), 16, 0, 0);
+    };
+    (void)rg;
+#else
+    auto item_load = [&](int i) { rg[i] = *reinterpret_cast<const f32x4*>((i < 4 ? ld_a : ld_w) + goff[i]); };
+    auto item_store_reg = [&](int i, unsigned char* buf) {
 #ifdef E3D_LAB_NO_STAGE
         if (K > 0) return;
 #endif
@@ -706,8 +730,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
         for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(buf + s * T_BYTES + dst[i]) = p[s];
 #endif
     };
+    auto item_store = item_store_reg;
+#endif
 
     cursor_bases();
+#ifdef E3D_LAB_PLANES_GLDS
+    // DMA distance 1: tile t+1 is fetched during k-step t (register staging runs its loads two tiles ahead)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) item_store(i, smem_raw);
+    cursor_advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
 #pragma unroll
     for (int i = 0; i < NI; ++i) item_load(i);
     cursor_advance();
@@ -717,6 +751,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
     for (int i = 0; i < NI; ++i) item_load(i);
     cursor_advance();
     __syncthreads();
+#endif
 
     int a_row[4], b_row[2];
 #pragma unroll
@@ -774,6 +809,9 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                 }
             }
             cursor_advance();
+#ifdef E3D_LAB_PLANES_GLDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this k-step's DMA pieces have landed (own wave's; the barrier covers the others)
+#endif
             __syncthreads();
             cur ^= 1;
         }
