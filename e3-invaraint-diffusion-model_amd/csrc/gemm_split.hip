@@ -775,6 +775,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned char* base = smem_raw + cur * BUF_BYTES;
             unsigned char* next = smem_raw + (cur ^ 1) * BUF_BYTES;
+#ifdef E3D_LAB_GLDS_PREFETCH   // lab, on top of PLANES_GLDS: the staging registers are free -- read the ks = 1 fragments early
+            typename Vec<E>::x8 fa1[NS][4], fb1[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    fb1[s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(base + (NS + s) * T_BYTES + swz_off(b_row[n], 2 + half));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    fa1[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 + half));
+            }
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 typename Vec<E>::x8 fa[NS][4], fb[NS][2];
@@ -788,6 +800,17 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                     for (int m = 0; m < 4; ++m)
                         fa[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 * ks + half));
                 }
+#ifdef E3D_LAB_GLDS_PREFETCH
+                if (ks == 1) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) fb[s][n] = fb1[s][n];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) fa[s][m] = fa1[s][m];
+                    }
+                }
+#endif
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int g = ks * 4 + m;   // MFMA group g stages item g: stream k-tile +1 out, +2 in
