@@ -1,0 +1,198 @@
+// Lab prototype (not product): the 256x256 persistent split GEMM with BOTH operands handed over as pre-split 16-bit planes
+// and staged by LDS-DMA (global_load_lds) through a ring of FOUR half-tile buffers (k16 each):
+//   * per k16 step a wave issues its 4 one-KB DMA pieces of half-tile h+3, reads the fragments of half-tile h+1 (landed
+//     and barriered one step earlier) and runs the 24 MFMAs of half-tile h from registers;
+//   * one counted wait (vmcnt(4): only the newest half-tile may still be in flight) and ONE raw s_barrier per k16 step --
+//     never vmcnt(0), never __syncthreads() inside the loop (it would drain the DMA queue);
+//   * no staging registers, no split arithmetic, no ds_write.
+// Operand layout ("k-tile interleaved planes", the bytes of an fp32 matrix): per row and k-tile of 32, 32 hi terms then 32 lo
+// terms.  out[M,N] = A . W^T (no bias / activation), three cross products hi*lo + lo*hi + hi*hi, fp32 accumulate.
+//   build:  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Ie3-invaraint-diffusion-model_amd/csrc -Iinclude \
+//               tools/lab/gemm_planes_glds4.hip -o lab_build/libgemm_glds4.so
+//   run:    python tools/lab/gemm_glds4_ab.py
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename E> struct V8;
+template <> struct V8<_Float16> { typedef f16x8 t; };
+template <> struct V8<__bf16> { typedef bf16x8 t; };
+__device__ __forceinline__ f32x16 mma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, slot = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+constexpr int BT = 256;
+constexpr int PLANE_B = BT * 32;            // one plane of a half-tile: 256 rows x 16 terms x 2 B
+constexpr int HB = 4 * PLANE_B;             // half-tile buffer: A hi, A lo, B hi, B lo = 32 KB
+constexpr int NBUF = 4;
+
+// 16-byte slot of (row, k-half) inside a plane: rows are 32 bytes; rows r and r + 8 use opposite slots, so the 16 rows a
+// ds_read_b128 lane group touches cover the 64 banks once
+__device__ __forceinline__ int frag_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
+
+template <typename E>
+__global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                   float* __restrict__ out, int N, int K, int tiles_m,
+                                                                   int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename V8<E>::t X8;
+    const int total = tiles_m * tiles_n, nk = K / 32, n_half = 2 * nk;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // DMA pieces of this wave: 4 per half-tile, 1 KB = 32 rows x 32 bytes of one plane
+    unsigned goff[4];
+    int dst[4];
+    bool is_a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wid * 4 + i, plane = piece >> 3, row = (piece & 7) * 32 + (lane >> 1), slot = lane & 1;
+        const int chunk = slot ^ ((row >> 3) & 1);
+        is_a[i] = plane < 2;
+        goff[i] = (unsigned)(row * K + (plane & 1) * 16 + chunk * 4);      // float units inside the k-tile; + 8 ks at issue time
+        dst[i] = __builtin_amdgcn_readfirstlane(plane * PLANE_B + (piece & 7) * 1024);
+    }
+
+    // DMA cursor: (tile, k-tile, k-half) of the next half-tile to fetch (wave-uniform)
+    int ld_tile = blockIdx.x, ld_k = 0, ld_ks = 0;
+    const float* ld_a;
+    const float* ld_w;
+    auto cursor_bases = [&]() {
+        const int lid = xcd_remap(ld_tile, total);
+        ld_a = A + (int64_t)(lid / tiles_n) * BT * K + ld_k * 32;
+        ld_w = W + (int64_t)(lid % tiles_n) * BT * K + ld_k * 32;
+    };
+    auto cursor_advance = [&]() {
+        if (ld_ks == 0) { ld_ks = 1; return; }
+        ld_ks = 0;
+        if (ld_k + 1 < nk) {
+            ++ld_k;
+            ld_a += 32;
+            ld_w += 32;
+        } else if (ld_tile + (int)gridDim.x < total) {
+            ld_tile += gridDim.x;
+            ld_k = 0;
+            cursor_bases();
+        } else {
+            ld_ks = 1;   // end of the stream: keep re-fetching its last half-tile (into buffers nobody reads again)
+        }
+    };
+    auto issue = [&](int buf) {
+        unsigned char* base = smem + buf * HB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* g = (is_a[i] ? ld_a : ld_w) + goff[i] + ld_ks * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+        }
+        cursor_advance();
+    };
+
+    int a_off[4], b_off[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_off[m] = frag_off(wr * 128 + m * 32 + l31, half);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b_off[n] = frag_off(wc * 64 + n * 32 + l31, half);
+    X8 fa[2][4], fb[2][2], fa_n[2][4], fb_n[2][2];     // [plane][m or n]: current half-tile / the next one
+    auto read_frags = [&](X8 (&xa)[2][4], X8 (&xb)[2][2], int buf) {
+        const unsigned char* base = smem + buf * HB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) xb[s][n] = *reinterpret_cast<const X8*>(base + (2 + s) * PLANE_B + b_off[n]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xa[s][m] = *reinterpret_cast<const X8*>(base + s * PLANE_B + a_off[m]);
+        }
+    };
+
+    // prologue: half-tiles 0, 1, 2 in flight; 0 and 1 landed and visible before the loop (frags(0) in registers)
+    cursor_bases();
+    issue(0);
+    issue(1);
+    issue(2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(fa, fb, 0);
+
+    int h = 0;   // global half-tile counter of the consumer (buffer = h & 3)
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+        for (int ht = 0; ht < n_half; ++ht, ++h) {
+            issue((h + 3) & 3);                       // buffer of half-tile h - 1: its fragments were read in step h - 2
+            read_frags(fa_n, fb_n, (h + 1) & 3);      // landed + barriered at the end of step h - 1
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);      // smallest terms first
+                    acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
+                }
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but this step's 4 pieces has landed: half-tile h + 2
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) fb[s][n] = fb_n[s][n];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) fa[s][m] = fa_n[s][m];
+            }
+        }
+
+        const int lid = xcd_remap(tile, total);
+        const int row0 = (lid / tiles_n) * BT, col0 = (lid % tiles_n) * BT;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = col0 + wc * 64 + n * 32 + l31;
+                float* o = out + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * N + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * N] = acc[m][n][r];
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing re-fetches before the LDS is released
+}
+
+}  // namespace
+
+extern "C" int lab_gemm_planes_glds4(const float* A, const float* W, float* out, int M, int N, int K, int f16, void* stream) {
+    if (M % BT || N % BT || K % 32 || K < 64) return -1;
+    int dev = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = cus / 8 * 8;
+    const int tiles_m = M / BT, tiles_n = N / BT, total = tiles_m * tiles_n;
+    const size_t lds = (size_t)NBUF * HB;
+    const dim3 grid(total < cus ? total : cus), block(512);
+    if (f16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_glds4_kernel<_Float16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gemm_planes_glds4_kernel<_Float16>, grid, block, lds, (hipStream_t)stream, A, W, out, N, K, tiles_m, tiles_n);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_glds4_kernel<__bf16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gemm_planes_glds4_kernel<__bf16>, grid, block, lds, (hipStream_t)stream, A, W, out, N, K, tiles_m, tiles_n);
+    }
+    return (int)hipGetLastError();
+}
