@@ -819,12 +819,23 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 #ifdef E3D_LAB_SETPRIO
                     __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef E3D_LAB_MFMA_INTERLEAVE
+                    // the three products of an accumulator two MFMAs apart instead of back to back (same order per
+                    // accumulator: bit-identical): a dependent MFMA waits for its predecessor's result
+                    acc[m][0] = mma16(fa[0][m], fb[1][0], acc[m][0]);
+                    acc[m][1] = mma16(fa[0][m], fb[1][1], acc[m][1]);
+                    acc[m][0] = mma16(fa[1][m], fb[0][0], acc[m][0]);
+                    acc[m][1] = mma16(fa[1][m], fb[0][1], acc[m][1]);
+                    acc[m][0] = mma16(fa[0][m], fb[0][0], acc[m][0]);
+                    acc[m][1] = mma16(fa[0][m], fb[0][1], acc[m][1]);
+#else
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
                         acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                     }
+#endif
 #ifdef E3D_LAB_SETPRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif

@@ -10,7 +10,7 @@ import __graft_entry__  # noqa: E402
 pkg = __graft_entry__.load_package()
 ops = pkg.ops
 DEV = "cuda:0"
-lab = ctypes.CDLL(os.path.join(ROOT, "lab_build", "libgemm_glds4.so"))
+lab = ctypes.CDLL(os.path.join(ROOT, "lab_build", os.environ.get("LAB_LIB", "libgemm_glds4.so")))
 lab.lab_gemm_planes_glds4.restype = ctypes.c_int
 lab.lab_gemm_planes_glds4.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 
@@ -19,7 +19,7 @@ def to_planes(x, dt):
     hi = x.to(dt)
     lo = (x - hi.float()).to(dt)
     R, K = x.shape
-    both = torch.stack([hi.view(R, K // 32, 32), lo.view(R, K // 32, 32)], dim=2)
+    both = torch.stack([hi.view(R, K // 16, 16), lo.view(R, K // 16, 16)], dim=2)      # [R, K/16, 2, 16]
     return both.contiguous().view(torch.float32).view(R, K)
 
 

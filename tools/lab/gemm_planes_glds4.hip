@@ -5,8 +5,7 @@
 //   * one counted wait (vmcnt(4): only the newest half-tile may still be in flight) and ONE raw s_barrier per k16 step --
 //     never vmcnt(0), never __syncthreads() inside the loop (it would drain the DMA queue);
 //   * no staging registers, no split arithmetic, no ds_write.
-// Operand layout ("k-tile interleaved planes", the bytes of an fp32 matrix): per row and k-tile of 32, 32 hi terms then 32 lo
-// terms.  out[M,N] = A . W^T (no bias / activation), three cross products hi*lo + lo*hi + hi*hi, fp32 accumulate.
+// Operand layout (the bytes of an fp32 matrix): per row and k16 block, 16 hi terms then 16 lo terms (64 contiguous bytes).  out[M,N] = A . W^T (no bias / activation), three cross products hi*lo + lo*hi + hi*hi, fp32 accumulate.
 //   build:  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Ie3-invaraint-diffusion-model_amd/csrc -Iinclude \
 //               tools/lab/gemm_planes_glds4.hip -o lab_build/libgemm_glds4.so
 //   run:    python tools/lab/gemm_glds4_ab.py
@@ -34,13 +33,18 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }
 
 constexpr int BT = 256;
-constexpr int PLANE_B = BT * 32;            // one plane of a half-tile: 256 rows x 16 terms x 2 B
-constexpr int HB = 4 * PLANE_B;             // half-tile buffer: A hi, A lo, B hi, B lo = 32 KB
-constexpr int NBUF = 4;
+constexpr int OPER_B = BT * 64;             // one operand of a half-tile: 256 rows x (16 hi + 16 lo terms) x 2 B
+constexpr int HB = 2 * OPER_B;              // half-tile buffer: A rows, B rows = 32 KB
+#ifndef LAB_NBUF
+#define LAB_NBUF 4
+#endif
+constexpr int NBUF = LAB_NBUF;            // 4: barrier every k16 step; 5 (= all 160 KB): issue distance 4, barrier every other step
 
-// 16-byte slot of (row, k-half) inside a plane: rows are 32 bytes; rows r and r + 8 use opposite slots, so the 16 rows a
-// ds_read_b128 lane group touches cover the 64 banks once
-__device__ __forceinline__ int frag_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
+// LDS rows are 64 bytes: [hi terms 0-7 | hi 8-15 | lo 0-7 | lo 8-15] with the four 16-byte slots XOR-swizzled by
+// (row >> 2) & 3 (the product kernel's rule: the 16 rows of a ds_read_b128 lane group cover the 64 banks once)
+__device__ __forceinline__ int frag_off(int row, int plane, int half) {
+    return row * 64 + (((plane * 2 + half) ^ ((row >> 2) & 3)) << 4);
+}
 
 template <typename E>
 __global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -53,81 +57,88 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* 
     const int wr = wid >> 2, wc = wid & 3;
     const int l31 = lane & 31, half = lane >> 5;
 
-    // DMA pieces of this wave: 4 per half-tile, 1 KB = 32 rows x 32 bytes of one plane
+    // DMA pieces of this wave: 4 per half-tile, 1 KB = 16 rows x 64 bytes (the row's hi and lo terms of one k16 block are
+    // 64 contiguous bytes in memory: operand layout [row][k16 block][plane][16 terms])
     unsigned goff[4];
     int dst[4];
     bool is_a[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int piece = wid * 4 + i, plane = piece >> 3, row = (piece & 7) * 32 + (lane >> 1), slot = lane & 1;
-        const int chunk = slot ^ ((row >> 3) & 1);
-        is_a[i] = plane < 2;
-        goff[i] = (unsigned)(row * K + (plane & 1) * 16 + chunk * 4);      // float units inside the k-tile; + 8 ks at issue time
-        dst[i] = __builtin_amdgcn_readfirstlane(plane * PLANE_B + (piece & 7) * 1024);
+        const int piece = wid * 4 + i, oper = piece >> 4, row = (piece & 15) * 16 + (lane >> 2), slot = lane & 3;
+        const int src_slot = slot ^ ((row >> 2) & 3);                      // which 16 bytes of the row's 64 land in this slot
+        is_a[i] = oper == 0;
+        goff[i] = (unsigned)(row * K + src_slot * 4);                     // float units inside the k16 block
+        dst[i] = __builtin_amdgcn_readfirstlane(oper * OPER_B + (piece & 15) * 1024);
     }
 
-    // DMA cursor: (tile, k-tile, k-half) of the next half-tile to fetch (wave-uniform)
-    int ld_tile = blockIdx.x, ld_k = 0, ld_ks = 0;
+    // DMA cursor: (tile, k16 block) of the next half-tile to fetch (wave-uniform)
+    int ld_tile = blockIdx.x, ld_k = 0;
     const float* ld_a;
     const float* ld_w;
     auto cursor_bases = [&]() {
         const int lid = xcd_remap(ld_tile, total);
-        ld_a = A + (int64_t)(lid / tiles_n) * BT * K + ld_k * 32;
-        ld_w = W + (int64_t)(lid % tiles_n) * BT * K + ld_k * 32;
+        ld_a = A + (int64_t)(lid / tiles_n) * BT * K + ld_k * 16;
+        ld_w = W + (int64_t)(lid % tiles_n) * BT * K + ld_k * 16;
     };
     auto cursor_advance = [&]() {
-        if (ld_ks == 0) { ld_ks = 1; return; }
-        ld_ks = 0;
-        if (ld_k + 1 < nk) {
+        if (ld_k + 1 < n_half) {
             ++ld_k;
-            ld_a += 32;
-            ld_w += 32;
+            ld_a += 16;
+            ld_w += 16;
         } else if (ld_tile + (int)gridDim.x < total) {
             ld_tile += gridDim.x;
             ld_k = 0;
             cursor_bases();
-        } else {
-            ld_ks = 1;   // end of the stream: keep re-fetching its last half-tile (into buffers nobody reads again)
-        }
+        }   // else: end of the stream: keep re-fetching its last half-tile (into buffers nobody reads again)
     };
     auto issue = [&](int buf) {
         unsigned char* base = smem + buf * HB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float* g = (is_a[i] ? ld_a : ld_w) + goff[i] + ld_ks * 8;
+            const float* g = (is_a[i] ? ld_a : ld_w) + goff[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
         }
         cursor_advance();
     };
 
-    int a_off[4], b_off[2];
+    int a_off[2][4], b_off[2][2];     // [plane][m or n]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a_off[m] = frag_off(wr * 128 + m * 32 + l31, half);
+    for (int s = 0; s < 2; ++s) {
 #pragma unroll
-    for (int n = 0; n < 2; ++n) b_off[n] = frag_off(wc * 64 + n * 32 + l31, half);
+        for (int m = 0; m < 4; ++m) a_off[s][m] = frag_off(wr * 128 + m * 32 + l31, s, half);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b_off[s][n] = OPER_B + frag_off(wc * 64 + n * 32 + l31, s, half);
+    }
     X8 fa[2][4], fb[2][2], fa_n[2][4], fb_n[2][2];     // [plane][m or n]: current half-tile / the next one
     auto read_frags = [&](X8 (&xa)[2][4], X8 (&xb)[2][2], int buf) {
         const unsigned char* base = smem + buf * HB;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) xb[s][n] = *reinterpret_cast<const X8*>(base + (2 + s) * PLANE_B + b_off[n]);
+            for (int n = 0; n < 2; ++n) xb[s][n] = *reinterpret_cast<const X8*>(base + b_off[s][n]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xa[s][m] = *reinterpret_cast<const X8*>(base + s * PLANE_B + a_off[m]);
+            for (int m = 0; m < 4; ++m) xa[s][m] = *reinterpret_cast<const X8*>(base + a_off[s][m]);
         }
     };
 
-    // prologue: half-tiles 0, 1, 2 in flight; 0 and 1 landed and visible before the loop (frags(0) in registers)
+    // prologue: NBUF - 1 half-tiles in flight; all but the newest landed and visible before the loop (frags(0) in registers)
     cursor_bases();
-    issue(0);
-    issue(1);
-    issue(2);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) issue(b);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(fa, fb, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // (step 1 of the 5-buffer form re-uses buffer 0 without another barrier in between)
 
-    int h = 0;   // global half-tile counter of the consumer (buffer = h & 3)
+    int h = 0;                        // global half-tile counter of the consumer
+    int b_next = 1, b_issue = NBUF - 1;   // ring positions of half-tile h + 1 (read) and h + NBUF - 1 (DMA target)
+#ifdef LAB_STAGGER
+    // the two waves of every SIMD (wr = 0 / wr = 1) run ONE BARRIER apart: while one group issues its DMA pieces and reads
+    // the next fragments (phase A), the other runs its 24 MFMAs (phase B) -- the matrix pipe always has a wave in phase B
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+#endif
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -138,8 +149,22 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* 
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
         for (int ht = 0; ht < n_half; ++ht, ++h) {
-            issue((h + 3) & 3);                       // buffer of half-tile h - 1: its fragments were read in step h - 2
-            read_frags(fa_n, fb_n, (h + 1) & 3);      // landed + barriered at the end of step h - 1
+            issue(b_issue);                           // the buffer of half-tile h - 1: its fragments were read in step h - 2
+            read_frags(fa_n, fb_n, b_next);           // landed + barriered earlier
+#ifdef LAB_STAGGER
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but this step's 4 pieces has landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef LAB_TERM_OUTER   // products outermost: 8 independent accumulators between two MFMAs on the same one (bit-identical)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = mma16(fa[t == 1 ? 1 : 0][m], fb[t == 0 ? 1 : 0][n], acc[m][n]);
+#else
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -148,8 +173,18 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* 
                     acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
                     acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                 }
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but this step's 4 pieces has landed: half-tile h + 2
+#endif
+#ifdef LAB_STAGGER
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+#else
+            if (NBUF == 4 || (h & 1)) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but this step's 4 pieces has landed
+                __builtin_amdgcn_s_barrier();
+            }
+#endif
+            b_next = b_next + 1 == NBUF ? 0 : b_next + 1;
+            b_issue = b_issue + 1 == NBUF ? 0 : b_issue + 1;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -171,6 +206,9 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_glds4_kernel(const float* 
                 for (int r = 0; r < 16; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * N] = acc[m][n][r];
             }
     }
+#ifdef LAB_STAGGER
+    if (wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the other group's extra barrier at the start
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing re-fetches before the LDS is released
 }
 
