@@ -787,9 +787,16 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                     fa1[s][m] = *reinterpret_cast<const typename Vec<E>::x8*>(base + s * T_BYTES + swz_off(a_row[m], 2 + half));
             }
 #endif
+#ifdef E3D_LAB_HALF_FRAGS   // timing only (results wrong): the ks = 1 block re-uses the ks = 0 fragments -- half the LDS reads
+            typename Vec<E>::x8 fa[NS][4], fb[NS][2];
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+#ifndef E3D_LAB_HALF_FRAGS
                 typename Vec<E>::x8 fa[NS][4], fb[NS][2];
+#else
+                if (ks == 0)
+#endif
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
 #pragma unroll
