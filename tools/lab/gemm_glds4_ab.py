@@ -11,8 +11,9 @@ pkg = __graft_entry__.load_package()
 ops = pkg.ops
 DEV = "cuda:0"
 lab = ctypes.CDLL(os.path.join(ROOT, "lab_build", os.environ.get("LAB_LIB", "libgemm_glds4.so")))
-lab.lab_gemm_planes_glds4.restype = ctypes.c_int
-lab.lab_gemm_planes_glds4.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+lab_fn = getattr(lab, os.environ.get("LAB_FN", "lab_gemm_planes_glds4"))
+lab_fn.restype = ctypes.c_int
+lab_fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 
 
 def to_planes(x, dt):
@@ -44,7 +45,7 @@ for f16, dt, mode in ((1, torch.float16, "f16x3"), (0, torch.bfloat16, "bf16x3")
         s = torch.cuda.current_stream().cuda_stream
 
         def run_lab():
-            rc = lab.lab_gemm_planes_glds4(ap.data_ptr(), wp.data_ptr(), out.data_ptr(), M, N, K, f16, s)
+            rc = lab_fn(ap.data_ptr(), wp.data_ptr(), out.data_ptr(), M, N, K, f16, s)
             assert rc == 0, rc
         run_lab(); torch.cuda.synchronize()
         prod = ops.gemm(a, w, None, mode=mode)
