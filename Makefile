@@ -1,5 +1,6 @@
 # Convenience targets (the driver calls __graft_entry__.build()/smoke(), pytest and bench.py directly).
 PY ?= python
+TAG ?= r02b
 
 build:            ## hipcc --offload-arch=gfx950 -> e3-invaraint-diffusion-model_amd/libe3d_hip.so
 	$(PY) -c "import __graft_entry__ as g; g.build()"
@@ -17,6 +18,6 @@ bench:            ## the headline line (one JSON object on stdout)
 	$(PY) bench.py
 
 profile:          ## rocprofv3 kernel stats + PMC traffic -> gpurun_out/prof_round, then profiles/
-	bash tools/profile_round.sh && $(PY) tools/profile_collect.py r01
+	bash tools/profile_round.sh && $(PY) tools/profile_collect.py $(TAG)
 
 .PHONY: build test-cpu test-gpu smoke bench profile
