@@ -279,8 +279,8 @@ class _Linear(torch.autograd.Function):
     the GEMM epilogue instead)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
-        z = ops.gemm(x, weight, bias, ops.ACT_NONE)
+    def forward(ctx, x, weight, bias, act, absmax=None):
+        z = ops.gemm(x, weight, bias, ops.ACT_NONE, absmax=absmax)
         ctx.act = act
         ctx.save_for_backward(x, weight, z if act != ops.ACT_NONE else None)
         ctx.has_bias = bias is not None
@@ -319,12 +319,12 @@ class _Linear(torch.autograd.Function):
                     q.add(dz[:, r0:r0 + w.shape[0]], x, w, b)
                     r0 += w.shape[0]
                 assert r0 == N
-                return dx, None, None, None
+                return dx, None, None, None, None
         if ctx.needs_input_grad[1]:
             dw = gemm_general(dz, True, x, True, N, K, M)                # dz^T [N,M] . x [M,K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dz)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _Attention(torch.autograd.Function):
@@ -339,12 +339,12 @@ class _Attention(torch.autograd.Function):
         return q_src, kv_src[:, :H], kv_src[:, H:]
 
     @staticmethod
-    def forward(ctx, q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p=0.0):
+    def forward(ctx, q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p=0.0, bounds=None):
         H = nh * 64
         q, k, v = _Attention._views(q_src, kv_src, H)
         drop = (float(drop_p), ops.next_dropout_seed()) if drop_p > 0 else (0.0, 0)
         out, lse = ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos,
-                                 want_lse=True, drop=drop)
+                                 want_lse=True, drop=drop, bounds=bounds)
         ctx.save_for_backward(q_src, kv_src, dist_emb, key_mask, out, lse)
         ctx.dims = (B, nh, Lq, Lk, max_pos)
         ctx.drop = drop
@@ -374,7 +374,7 @@ class _Attention(torch.autograd.Function):
                 _p(dq), Lq * dq.stride(0), dq.stride(0), _p(dk), Lk * dk.stride(0), dk.stride(0),
                 _p(dv), Lk * dv.stride(0), dv.stride(0), _p(dE), _p(ws), B, nh, Lq, Lk, ctx.terms, ctx.drop[0], ctx.drop[1],
                 _stream()), "e3d_relkey_attn_bwd_ex")
-        return dq_src, dkv_src, dE, None, None, None, None, None, None, None
+        return dq_src, dkv_src, dE, None, None, None, None, None, None, None, None
 
 
 class _Dropout(torch.autograd.Function):
@@ -469,20 +469,32 @@ def _needs_grad(*tensors):
 
 class functional:
     @staticmethod
-    def linear(x, weight, bias=None, act=ops.ACT_NONE):
+    def linear(x, weight, bias=None, act=ops.ACT_NONE, absmax=None):
+        """``absmax`` (ops.absmax_slot): raised to the largest |output| (act = none); the result then carries it as
+        ``_e3d_absmax`` for ``attention`` (q / k projections)."""
         if _needs_grad(x, weight, bias):
-            return _Linear.apply(x, weight, bias, act)
-        return ops.gemm(x, weight, bias, act)
+            out = _Linear.apply(x, weight, bias, act, absmax)
+        else:
+            out = ops.gemm(x, weight, bias, act, absmax=absmax)
+        if absmax is not None:
+            out._e3d_absmax = absmax
+        return out
 
     @staticmethod
     def attention(q_src, kv_src, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, drop_p=0.0):
         """q_src = packed qkv [B*L,3H] (kv_src None, self-attention) or q [B*Lq,H] with packed kv [B*Lk,2H].
         ``drop_p`` > 0 (training): dropout on the attention probabilities."""
+        # element bounds left by the projections (functional.linear(..., absmax=)): they let the kernels skip all-padding
+        # key tiles when that is provably exact; absent (direct callers) = full sweep
+        q_abs = getattr(q_src, "_e3d_absmax", None)
+        k_abs = q_abs if kv_src is None else getattr(kv_src, "_e3d_absmax", None)
+        bounds = (q_abs, k_abs) if q_abs is not None and k_abs is not None else None
         if _needs_grad(q_src, kv_src, dist_emb):
-            return _Attention.apply(q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p)
+            return _Attention.apply(q_src, kv_src, dist_emb, key_mask, B, nh, Lq, Lk, max_pos, drop_p, bounds)
         q, k, v = _Attention._views(q_src, kv_src, nh * 64)
         drop = (float(drop_p), ops.next_dropout_seed()) if drop_p > 0 else None
-        return ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos, drop=drop)
+        return ops.attention(q, k, v, B, nh, Lq, Lk, key_mask=key_mask, dist_emb=dist_emb, max_pos=max_pos, drop=drop,
+                             bounds=bounds)
 
     @staticmethod
     def dropout(x, p, training=True):

@@ -166,7 +166,7 @@ def run_self_attention(att, x, mask, B, L, drop=(0.0, 0.0)):
     fused relative-key attention -> out-proj GEMM -> residual + LayerNorm."""
     sa = att.self
     w, b = qkv_weights(sa)
-    qkv = F.linear(x, w, b)
+    qkv = F.linear(x, w, b, absmax=ops.absmax_slot(sa, "qkv", x.device))
     relkey = sa.position_embedding_type == "relative_key"
     ctx = F.attention(qkv, None, B, att.num_heads, L, L, key_mask=mask,
                       dist_emb=sa.distance_embedding.weight if relkey else None,
@@ -178,11 +178,12 @@ def project_cross_kv(att, enc):
     """K/V projection of the encoder states for one decoder layer -> [B*Lk, 2H].  It depends on
     neither the timestep nor the noised ligand, so samplers compute it once."""
     w, b = kv_weights(att.self)
-    return F.linear(enc, w, b)
+    # (a scalar of its own, not a pool slot: samplers keep this projection -- and its bound -- for a whole chain)
+    return F.linear(enc, w, b, absmax=torch.zeros(1, device=enc.device, dtype=torch.float32))
 
 
 def run_cross_attention(att, x, kv, enc_mask, B, Lq, Lk, drop=(0.0, 0.0)):
-    q = F.linear(x, att.self.query.weight, att.self.query.bias)
+    q = F.linear(x, att.self.query.weight, att.self.query.bias, absmax=ops.absmax_slot(att.self, "q", x.device))
     ctx = F.attention(q, kv, B, att.num_heads, Lq, Lk, key_mask=enc_mask, drop_p=drop[1])
     return _attention_output(att, ctx, x, drop[0])
 

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq,
-    int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dDrop drop) {
+    int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dBounds bnd, E3dDrop drop) {
     typedef typename AV<E>::x8 bf16x8;   // (name kept from the bf16 form: 8 split terms of type E)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -208,12 +208,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
         for (int r = 0; r < 16; ++r) ring[(32 + mfma32_row(r, half)) * RING_LD + qi] = t[r];
     }
 
-    // Trailing key tiles that are padding in every position contribute exp(-10000 - m) == 0.0f exactly
-    // (fp32 underflow), so the sweep stops after the tile of the last valid key.  The result is bit-identical
-    // to the full sweep; an all-padding item (no valid key) keeps the full sweep, as the reference then
-    // softmaxes the uniformly shifted scores.
+    // Trailing key tiles that are padding in every position contribute exp(s - 10000 - m) == 0.0f exactly
+    // (fp32 underflow) AS LONG AS the scores of a row spread over less than ~9900 -- the reference's mask is additive
+    // (structure_model/model.py:226-231), so with |q|, |k| in the thousands a padded key does reach the softmax, and
+    // skipping it would be wrong (found at 0.47 max-norm in the weights-x4 regime of the margin test).  The sweep stops
+    // after the tile of the last valid key only when the caller's element bounds prove the spread small
+    // (e3d_mask_skip_is_exact); the result is then bit-identical to the full sweep.  An all-padding item (no valid key)
+    // keeps the full sweep, as the reference then softmaxes the uniformly shifted scores.
     int k_tiles = (Lk + 31) >> 5;
-    if (mb && skip_padded_tiles) {
+    if (mb && skip_padded_tiles && e3d_mask_skip_is_exact(bnd)) {
         int last = -1;
         for (int base = 0; base < Lk; base += 64) {
             const int key = base + lane;
@@ -335,7 +338,7 @@ int g_skip_padded = 1;
 template <int NS, bool DROP = false, typename E = __bf16>
 int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
            int64_t v_bs, int64_t v_rs, const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
-           int B, int nh, int Lq, int Lk, hipStream_t s, E3dDrop drop = E3dDrop{0, 0, 1.f}) {
+           int B, int nh, int Lq, int Lk, E3dBounds bnd, hipStream_t s, E3dDrop drop = E3dDrop{0, 0, 1.f}) {
     const int q_tiles = (Lq + 31) / 32;
     const int n_units = B * nh * q_tiles;
     const int wpb = 4;
@@ -343,10 +346,10 @@ int launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k
     const size_t lds = (size_t)wpb * WAVE_LDS_F * sizeof(float);
     if (dist_emb)
         hipLaunchKernelGGL((attn_fwd_split_kernel<NS, true, DROP, E>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, bnd, drop);
     else
         hipLaunchKernelGGL((attn_fwd_split_kernel<NS, false, DROP, E>), dim3(n_blocks), dim3(64 * wpb), lds, s, q, q_bs, q_rs, k,
-                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, drop);
+                           k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, nh, Lq, Lk, q_tiles, n_units, g_skip_padded, bnd, drop);
     return e3d_launch_status("e3d_relkey_attn_fwd_split");
 }
 
@@ -362,7 +365,10 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
                                             int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                             const float* dist_emb, int P, const float* key_mask, float* out,
                                             float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
-                                            uint64_t drop_seed, void* e_scratch, int e_scratch_ready, void* stream) {
+                                            uint64_t drop_seed, void* e_scratch, int e_scratch_ready, const float* q_absmax,
+                                            const float* k_absmax, const float* e_absmax, void* stream) {
+    const E3dBounds bnd{q_absmax, k_absmax, dist_emb ? e_absmax : nullptr};
+    E3D_REQUIRE(!dist_emb || !q_absmax || e_absmax, "attn_split: rel-key attention with element bounds needs e_absmax too");
     E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_split: drop_p=%g outside [0, 1)", (double)drop_p);
     E3D_REQUIRE(q && k && v && out, "attn_split: null pointer");
     E3D_REQUIRE(B > 0 && nh > 0 && Lq > 0 && Lk > 0, "attn_split: bad shape B=%d nh=%d Lq=%d Lk=%d", B, nh, Lq, Lk);
@@ -389,8 +395,8 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     if (drop_p > 0.f) {   // training with attention-probability dropout: per-wave kernel
         const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
         if (terms == 3)
-            return launch<2, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s, d);
-        return launch<3, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s, d);
+            return launch<2, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
+        return launch<3, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
     }
     static int coop = -1;   // E3D_ATTN_COOP=0: per-wave kernel below for every shape (A/B experiments)
     if (coop < 0) {
@@ -403,13 +409,13 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     if ((terms == 3 || f16) && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1) &&
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, g_skip_padded, e_scratch, e_scratch_ready, f16, s);
+                                    Lq, Lk, g_skip_padded, bnd, e_scratch, e_scratch_ready, f16, s);
     if (f16)
         return launch<2, false, _Float16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
-                                          Lq, Lk, s);
+                                          Lq, Lk, bnd, s);
     if (terms == 3)
-        return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
-    return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, s);
+        return launch<2>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s);
+    return launch<3>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s);
 }
 
 extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
@@ -417,7 +423,7 @@ extern "C" int e3d_relkey_attn_fwd_split(const float* q, int64_t q_bs, int64_t q
                                          const float* dist_emb, int P, const float* key_mask, float* out, float* lse,
                                          int B, int nh, int Lq, int Lk, int terms, void* stream) {
     return e3d_relkey_attn_fwd_split_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B,
-                                        nh, Lq, Lk, terms, 0.f, 0, nullptr, 0, stream);
+                                        nh, Lq, Lk, terms, 0.f, 0, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
@@ -426,5 +432,5 @@ extern "C" int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int6
                                               float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                               uint64_t drop_seed, void* stream) {
     return e3d_relkey_attn_fwd_split_ex(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B,
-                                        nh, Lq, Lk, terms, drop_p, drop_seed, nullptr, 0, stream);
+                                        nh, Lq, Lk, terms, drop_p, drop_seed, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }

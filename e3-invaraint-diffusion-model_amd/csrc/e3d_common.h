@@ -13,11 +13,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void e3d_set_error(const char* fmt, ...);
 
+// device scalars bounding |Q|, |K| and |distance table| elements of an attention call (e3d_mask_skip_is_exact below)
+struct E3dBounds { const float* q; const float* k; const float* e; };
+
 // attn_relkey_coop.hip: workgroup-cooperative bf16x3 attention forward (internal; arguments validated by the caller)
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         void* e_scratch, int e_ready, int f16, hipStream_t s);
+                         struct E3dBounds bnd, void* e_scratch, int e_ready, int f16, hipStream_t s);
 
 #define E3D_REQUIRE(cond, ...)       \
     do {                             \
@@ -122,6 +125,36 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// ---------------------------------------------------------------- running |x| maximum of a kernel's outputs
+// GEMM epilogues can report the largest |out| they wrote (``absmax`` arguments of the *_ex entry points) so that the
+// attention kernels can PROVE that a padded key cannot reach the softmax of a valid one before they skip all-padding key
+// tiles: the reference masks additively with -10000 (structure_model/model.py:226-231), which only silences a key
+// while the score spread stays below ~9900.  Kept as the bit pattern of |x| in an unsigned: the integer order equals
+// the float order for finite values and puts inf / NaN above everything (a NaN anywhere then reads as "no bound").
+// The target is only ever raised (atomic max): a value left over from an earlier, larger launch is a valid bound too.
+__device__ __forceinline__ void e3d_absmax_accum(unsigned& m, float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    m = m > b ? m : b;
+}
+__device__ __forceinline__ void e3d_absmax_commit(unsigned m, float* target, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = m > t ? m : t;
+    }
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(target), m);
+}
+// May all-padding key tiles be skipped?  Scores are s = (q.k + q.e) / 8 with |q.k| <= 64 qa ka and |q.e| <= 64 qa ea
+// (qa, ka, ea: largest |element| of Q, K and the distance table), so any two scores of a row differ by at most
+// 16 qa (ka + ea); a padded key contributes exp(s_pad - 10000 - m) with m >= the row's valid scores, which is 0.0f --
+// also without flush-to-zero, exp(-104) < 2^-149 -- while 16 qa (ka + ea) < 10000 - 104.  Missing bounds (null) or a
+// NaN / inf bound: no skipping, the full sweep is always exact.
+__device__ __forceinline__ bool e3d_mask_skip_is_exact(const E3dBounds b) {
+    if (!b.q || !b.k) return false;
+    const float qa = *b.q, ka = *b.k, ea = b.e ? *b.e : 0.f;
+    return 16.0f * qa * (ka + ea) < 9890.0f;   // false for NaN
 }
 
 // ---------------------------------------------------------------- dropout decisions

@@ -81,7 +81,8 @@ template <int ACT, typename E>
 __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M, int N, int K,
-                                                         int tiles_n, int k_slice, int to_slabs, float* __restrict__ slabs) {
+                                                         int tiles_n, int k_slice, int to_slabs, float* __restrict__ slabs,
+                                                         float* __restrict__ absmax) {
     typedef typename SV<E>::x8 X8;
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile % tiles_n;
@@ -139,14 +140,19 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict
     }
     const int col = tn * 32 + l31;     // a single slice covers K: finish here
     const float bv = bias ? bias[col] : 0.f;
+    unsigned amax = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = tm * 32 + mfma32_row(r, half);
         float v = acc[r] + bv;
         if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
         if (ACT == E3D_ACT_SILU) v = silu(v);
-        if (row < M) out[(int64_t)row * ldc + col] = v;
+        if (row < M) {
+            out[(int64_t)row * ldc + col] = v;
+            if (ACT == E3D_ACT_NONE && absmax) e3d_absmax_accum(amax, v);
+        }
     }
+    if (ACT == E3D_ACT_NONE && absmax) e3d_absmax_commit(amax, absmax, lane);
 }
 
 // second launch, plain form: one wave per (output row, 256-column chunk), a lane finishes 4 consecutive columns
@@ -154,20 +160,25 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict
 template <int ACT>
 __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restrict__ slabs, int n_slices, int tiles_n,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int64_t ldc, int M, int N) {
+                                                            int64_t ldc, int M, int N, float* __restrict__ absmax) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c0 = blockIdx.y * 256 + 4 * lane;
-    if (row >= M || c0 >= N) return;
-    const float* p = slabs + ((int64_t)(row >> 5) * tiles_n + (c0 >> 5)) * n_slices * 1024 + slab_offset(row & 31, c0 & 31);
-    f32x4 v = slab_sum(p, n_slices);
-    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
+    if (row >= M) return;        // (wave-uniform)
+    unsigned amax = 0;           // lanes past the last column stay in the wave for the |out| maximum
+    if (c0 < N) {
+        const float* p = slabs + ((int64_t)(row >> 5) * tiles_n + (c0 >> 5)) * n_slices * 1024 + slab_offset(row & 31, c0 & 31);
+        f32x4 v = slab_sum(p, n_slices);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (ACT == E3D_ACT_GELU) v[j] = gelu_erf(v[j]);
-        if (ACT == E3D_ACT_SILU) v[j] = silu(v[j]);
+        for (int j = 0; j < 4; ++j) {
+            if (ACT == E3D_ACT_GELU) v[j] = gelu_erf(v[j]);
+            if (ACT == E3D_ACT_SILU) v[j] = silu(v[j]);
+            if (ACT == E3D_ACT_NONE) e3d_absmax_accum(amax, v[j]);
+        }
+        *reinterpret_cast<f32x4*>(out + (int64_t)row * ldc + c0) = v;
     }
-    *reinterpret_cast<f32x4*>(out + (int64_t)row * ldc + c0) = v;
+    if (ACT == E3D_ACT_NONE && absmax) e3d_absmax_commit(amax, absmax, lane);
 }
 
 // second launch, BertSelfOutput / BertOutput form: out = LayerNorm(sum of slices + bias + residual) * gamma + beta.
@@ -244,12 +255,12 @@ Plan make_plan(int M, int N, int K) {
 
 template <typename E>
 int launch_partials(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-                    int K, int act, const Plan& p, int to_slabs, float* slabs, hipStream_t s) {
+                    int K, int act, const Plan& p, int to_slabs, float* slabs, float* absmax, hipStream_t s) {
     const dim3 grid(p.tiles, p.slices), block(64);
 #define E3D_SKINNY_CASE(a)                                                                                              \
     case a:                                                                                                             \
         hipLaunchKernelGGL((gemm_skinny_kernel<a, E>), grid, block, 0, s, A, lda, W, bias, out, ldc, M, N, K, p.tiles_n, \
-                           p.k_slice, to_slabs, slabs);                                                                  \
+                           p.k_slice, to_slabs, slabs, absmax);                                                                \
         break
     switch (act) {
         E3D_SKINNY_CASE(E3D_ACT_NONE);
@@ -290,10 +301,11 @@ extern "C" int64_t e3d_gemm_skinny_workspace_bytes(int M, int N, int K) {
     return (int64_t)p.tiles * p.slices * 1024 * sizeof(float);
 }
 
-extern "C" int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const float* W, const float* bias, float* out,
-                                         int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
-                                         int64_t workspace_bytes, void* stream) {
+extern "C" int e3d_gemm_skinny_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
+                                            int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
+                                            int64_t workspace_bytes, float* absmax, void* stream) {
     if (check_common(A, lda, W, out, M, N, K, terms, workspace, workspace_bytes)) return -1;
+    E3D_REQUIRE(!absmax || act == E3D_ACT_NONE, "gemm_skinny: out_absmax exists for act = none");
     E3D_REQUIRE(ldc >= N && ldc % 4 == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
                 "gemm_skinny: out / bias must be 16-byte aligned, ldc %% 4 == 0 (ldc=%lld)", (long long)ldc);
     hipStream_t s = (hipStream_t)stream;
@@ -301,18 +313,25 @@ extern "C" int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const floa
     float* slabs = reinterpret_cast<float*>(workspace);
     const int to_slabs = p.slices > 1;
     const int rc = terms == E3D_TERMS_F16X3
-                       ? launch_partials<_Float16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, s)
-                       : launch_partials<__bf16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, s);
+                       ? launch_partials<_Float16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, s)
+                       : launch_partials<__bf16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, s);
     if (rc) return rc;
     if (to_slabs) {
         const dim3 grid((M + 3) / 4, (N + 255) / 256), block(256);
         switch (act) {
-            case E3D_ACT_NONE: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_NONE>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N); break;
-            case E3D_ACT_GELU: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_GELU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N); break;
-            default: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_SILU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N); break;
+            case E3D_ACT_NONE: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_NONE>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
+            case E3D_ACT_GELU: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_GELU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
+            default: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_SILU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
         }
     }
     return e3d_launch_status("e3d_gemm_skinny_f32_split");
+}
+
+extern "C" int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const float* W, const float* bias, float* out,
+                                         int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+    return e3d_gemm_skinny_f32_split_ex(A, lda, W, bias, out, ldc, M, N, K, act, terms, workspace, workspace_bytes, nullptr,
+                                        stream);
 }
 
 extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
@@ -326,8 +345,8 @@ extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int6
     const Plan p = make_plan(M, H, K);
     float* slabs = reinterpret_cast<float*>(workspace);
     const int rc = terms == E3D_TERMS_F16X3
-                       ? launch_partials<_Float16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, s)
-                       : launch_partials<__bf16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, s);
+                       ? launch_partials<_Float16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, s)
+                       : launch_partials<__bf16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, s);
     if (rc) return rc;
     const dim3 grid((M + 3) / 4), block(256);
     switch (H) {

@@ -280,3 +280,20 @@ extern "C" int e3d_head_linear_fwd(const float* x, const float* W, const float* 
                                      Nout));
     return e3d_launch_status("e3d_head_linear_fwd");
 }
+
+// ------------------------------------------------------------------------------------------------ |x| maximum
+namespace {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ target) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) e3d_absmax_accum(m, x[i]);
+    e3d_absmax_commit(m, target, threadIdx.x & 63);
+}
+}  // namespace
+
+extern "C" int e3d_absmax_f32(const float* x, int64_t n, float* target, void* stream) {
+    E3D_REQUIRE(x && target && n > 0, "absmax: bad arguments");
+    int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, target);
+    return e3d_launch_status("e3d_absmax_f32");
+}

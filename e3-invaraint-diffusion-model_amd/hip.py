@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3D_HIP_LIB", os.path.join(_HERE, "libe3d_hip.so"))   # override: kernel experiments
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 _SIGNATURES = {
@@ -18,12 +18,15 @@ _SIGNATURES = {
     "e3d_last_error": (c_char_p, []),
     "e3d_gemm_bias_act_f32": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "e3d_gemm_bias_act_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
+    "e3d_gemm_bias_act_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "e3d_absmax_f32": (c_int, [_P, c_int64, _P, _P]),
     "e3d_relkey_attn_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                     _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "e3d_relkey_attn_fwd_split": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                           _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "e3d_gemm_skinny_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "e3d_gemm_skinny_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
+    "e3d_gemm_skinny_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
     "e3d_gemm_skinny_plan_select": (None, [c_int, c_int]),
     "e3d_gemm_skinny_residual_layernorm_f32_split": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int,
                                                      c_int, _P, c_int64, _P]),
@@ -50,7 +53,7 @@ _SIGNATURES = {
                                                c_uint64, _P]),
     "e3d_relkey_attn_fwd_split_ex": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                              _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float,
-                                             c_uint64, _P, c_int, _P]),
+                                             c_uint64, _P, c_int, _P, _P, _P, _P]),
     "e3d_attn_scratch_bytes": (c_int64, [c_int]),
     "e3d_ddpm_step_wrap_table": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int64, _P]),
     "e3d_relkey_attn_bwd_drop": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,

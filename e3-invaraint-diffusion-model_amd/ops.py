@@ -115,6 +115,53 @@ except ImportError:      # very old torch: training.fit() bumps the generation a
     pass
 
 
+# ---------------------------------------------------------------------------------------------- |out| bounds
+# The attention kernels may skip key tiles that are padding in every position only when that is exact: the reference
+# masks additively with -10000 (structure_model/model.py:226-231), so a padded key stays out of the softmax only while
+# the scores of a row spread over less than ~9900 (include/e3d_hip.h, e3d_attn_skip_padded_tiles).  The proof comes from
+# the GEMMs that produce Q and K: launched with ``absmax=<slot>`` they raise a device scalar to the largest |output|
+# (atomic max in the epilogue), the attention call reads the scalars on the device.  Slots are one float each in a
+# per-device pool, handed out once per owner (a BertSelfAttention module) and only ever raised by the kernels:
+# ``reset_absmax()`` (one fill launch) zeroes them all -- models call it once per batch / sampling chain, so a slot holds
+# the running maximum of that chain.  A stale (too large) value is still a valid bound: it can only cost the skip.
+_ABSMAX_POOLS = {}      # device index -> [pool tensor, slots handed out]
+ABSMAX_POOL_SLOTS = 4096
+
+
+def absmax_slot(owner, name, device):
+    """The device scalar (1-element view) that bounds |outputs| of ``owner``'s projection ``name``."""
+    slots = owner.__dict__.setdefault("_e3d_absmax", {})
+    key = (name, device.index)
+    t = slots.get(key)
+    if t is None:
+        ent = _ABSMAX_POOLS.get(device.index)
+        if ent is None:
+            ent = _ABSMAX_POOLS[device.index] = [torch.zeros(ABSMAX_POOL_SLOTS, device=device, dtype=torch.float32), 0]
+        if ent[1] >= ABSMAX_POOL_SLOTS:
+            raise RuntimeError("absmax pool exhausted")
+        t = slots[key] = ent[0][ent[1]:ent[1] + 1]
+        ent[1] += 1
+    return t
+
+
+def reset_absmax(device=None):
+    """Zero every slot of the device's pool (one launch): the start of a batch or of a sampling chain."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    ent = _ABSMAX_POOLS.get(idx)
+    if ent is not None:
+        ent[0].zero_()
+
+
+def absmax(x, target=None):
+    """max(target, max |x|) as a 1-element device tensor (e3d_absmax_f32); NaN / inf in x give NaN / inf."""
+    _chk(x, "absmax.x")
+    assert x.is_contiguous()
+    if target is None:
+        target = torch.zeros(1, device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().e3d_absmax_f32(_p(x), x.numel(), _p(target), _stream()), "e3d_absmax_f32")
+    return target
+
+
 # GEMM arithmetic: "f32" = exact fp32 MFMA; "bf16x3" / "bf16x6" = fp32 operands split into 2 / 3
 # bf16 terms on the bf16 matrix cores with fp32 accumulation (gemm_split.hip).  bf16x6 is fp32-grade
 # (4e-7 end-to-end vs 1.8e-6 for fp32 itself), bf16x3 ~2.6e-5 end-to-end (tolerance 1e-4).
@@ -162,8 +209,10 @@ def _skinny_ok(terms, M, N, K, a):
             and -(-M // 32) * (N // 32) <= SKINNY_MAX_TILES)
 
 
-def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
-    """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view."""
+def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None):
+    """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view.  ``absmax`` (1-element
+    device tensor, act = none): raised to the largest |out| by the kernel's epilogue (split arithmetics; the exact-f32
+    kernels have no use for it -- their attention twin never skips key tiles)."""
     _chk(a, "gemm.a"); _chk(weight, "gemm.weight"); _chk(bias, "gemm.bias")
     assert a.dim() == 2 and a.stride(1) == 1 and weight.is_contiguous()
     M, K = a.shape
@@ -173,19 +222,22 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None):
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
     terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
+    if absmax is not None:
+        _chk(absmax, "gemm.absmax")
+        assert act == ACT_NONE and absmax.numel() == 1
     with _timed("gemm", (M, N, K, act)):
         if _skinny_ok(terms, M, N, K, a) and out.stride(0) % 4 == 0:
             ws = _skinny_workspace(a.device, M, N, K)
-            hip.check(hip.lib().e3d_gemm_skinny_f32_split(_p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0),
-                                                          M, N, K, act, terms, _p(ws), ws.numel(), _stream()),
-                      "e3d_gemm_skinny_f32_split")
+            hip.check(hip.lib().e3d_gemm_skinny_f32_split_ex(_p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0),
+                                                             M, N, K, act, terms, _p(ws), ws.numel(), _p(absmax), _stream()),
+                      "e3d_gemm_skinny_f32_split_ex")
         elif terms == 0:
             hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
                                                       out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
         else:
-            hip.check(hip.lib().e3d_gemm_bias_act_f32_split(
-                _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _stream()),
-                "e3d_gemm_bias_act_f32_split")
+            hip.check(hip.lib().e3d_gemm_bias_act_f32_split_ex(
+                _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _p(absmax), _stream()),
+                "e3d_gemm_bias_act_f32_split_ex")
     return out
 
 
@@ -244,10 +296,14 @@ def attn_dropout_mask(B, nh, Lq, Lk, p, seed, device="cuda"):
     return out
 
 
-def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False, mode=None, drop=None):
+def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, want_lse=False, mode=None, drop=None,
+              bounds=None):
     """q [B*Lq, >=nh*64] / k, v [B*Lk, ...] row-strided 2-D views (e.g. slices of a fused QKV
     buffer).  Returns ctx [B*Lq, nh*64] (and lse [B,nh,Lq]).  ``drop`` = (p, seed): dropout on the
-    normalised probabilities (training); the exact-fp32 mode then runs its fp32-grade bf16x6 twin."""
+    normalised probabilities (training); the exact-fp32 mode then runs its fp32-grade bf16x6 twin.
+    ``bounds`` = (q_absmax, k_absmax): 1-element device tensors bounding |element| of the Q rows and of ALL K rows
+    (``gemm(..., absmax=)``); with them the split kernels skip all-padding key tiles when that is provably exact,
+    without them every call sweeps all keys."""
     for n, t in (("q", q), ("k", k), ("v", v), ("key_mask", key_mask), ("dist_emb", dist_emb)):
         _chk(t, "attention." + n)
     assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
@@ -269,22 +325,29 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
         else:
             # scratch for the bf16 planes of dist_emb (cooperative kernel): a torch allocation keeps the call
             # free of stream-ordered hipMallocAsync, so the launch sequence can be captured into a HIP graph
-            scratch, ready = None, 0
+            scratch, ready, e_abs = None, 0, None
+            q_abs, k_abs = bounds if bounds is not None else (None, None)
             if dist_emb is not None:
                 # inference (grad disabled): the planes are kept across calls, keyed by the tensor's version / storage
                 infer = not torch.is_grad_enabled()
                 ent = getattr(dist_emb, "_e3d_planes", None) if infer else None
                 if ent is not None and ent[0] == weight_key(dist_emb) + (Lk, terms):
-                    scratch, ready = ent[1], 1
+                    scratch, ready, e_abs = ent[1], 1, ent[2]
                 else:
                     scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
+                    e_abs = absmax(dist_emb.detach()) if q_abs is not None else None
                     if infer and not torch.cuda.is_current_stream_capturing():
                         try:
-                            dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk, terms), scratch)
+                            if e_abs is None:
+                                e_abs = absmax(dist_emb.detach())
+                            dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk, terms), scratch, e_abs)
                         except AttributeError:
                             pass
             p, seed = (float(drop[0]), int(drop[1])) if dropping else (0.0, 0)
-            hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), ready, _stream()),
+            if q_abs is None or k_abs is None or (dist_emb is not None and e_abs is None):
+                q_abs = k_abs = e_abs = None
+            hip.check(hip.lib().e3d_relkey_attn_fwd_split_ex(*args, terms or 6, p, seed, _p(scratch), ready, _p(q_abs),
+                                                             _p(k_abs), _p(e_abs), _stream()),
                       "e3d_relkey_attn_fwd_split_ex")
     return (out, lse) if want_lse else out
 

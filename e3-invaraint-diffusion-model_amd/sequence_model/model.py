@@ -59,6 +59,7 @@ class ConditionalBertForDiffusionBase(nn.Module):
                     receptor_angle, receptor_attention_masks)
         B, L = noised_ligand_seq.shape[:2]
         Lr = receptor_seq.shape[1]
+        ops.reset_absmax(noised_ligand_seq.device)   # |Q|, |K| bounds of the attention calls: fresh per forward
         lig_mask = ligand_attention_masks.contiguous().float()
         rec_mask = receptor_attention_masks.contiguous().float()
         temb = self.timestep_projector(timestep.squeeze(dim=-1)).contiguous()            # [B,H]

@@ -9,7 +9,7 @@ from typing import List
 import torch
 from torch import nn
 
-from .. import bert
+from .. import bert, ops
 from ..blocks import (BertEmbeddings, GaussianFourierProjection, Predictor, SELayer, flat2d,
                       require_gpu)
 from ..training import adamw
@@ -48,6 +48,7 @@ class ConditionalBertForDiffusionBase(nn.Module):
         """reference model.py:191-200 (+ the decoder layers' cross K/V projections)."""
         require_gpu(receptor_seq, receptor_angles, receptor_attention_masks)
         B, L = receptor_angles.shape[:2]
+        ops.reset_absmax(receptor_angles.device)   # |Q|, |K| bounds of the attention calls: fresh per batch / chain
         mask = receptor_attention_masks.contiguous().float()
         ang = self.receptor_angle_emb.run(flat2d(receptor_angles))
         seq = self.receptor_seq_emb.run(flat2d(receptor_seq))

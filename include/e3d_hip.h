@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define E3D_ABI_VERSION 1
+#define E3D_ABI_VERSION 2
 
 /* ``terms`` of the split-operand entry points: how an fp32 operand enters the 16-bit matrix cores.
  *   3  (bf16x3): 2 bf16 terms, 3 cross products, ~2^-17 per product, fp32 exponent range;
@@ -59,6 +59,17 @@ int e3d_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const flo
 int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
                                 float* out, int64_t ldc, int M, int N, int K, int act, int terms,
                                 void* stream);
+
+/* e3d_gemm_bias_act_f32_split that also reports the largest |out| it wrote: ``out_absmax`` (device, one float, may be
+ * NULL) is raised atomically to max(*out_absmax, max |out[m][n]|) -- never lowered, so the caller zeroes it when it wants
+ * a fresh figure; a NaN / inf output leaves a NaN / inf there.  act must be E3D_ACT_NONE when out_absmax is given.
+ * Purpose: the bounds of e3d_relkey_attn_fwd_split_ex (below), which let the attention kernels skip all-padding key
+ * tiles only when that is provably exact.  Costs two integer VALU operations per output element. */
+int e3d_gemm_bias_act_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
+                                   int64_t ldc, int M, int N, int K, int act, int terms, float* out_absmax,
+                                   void* stream);
+/* target = max(target, max_i |x[i]|), same conventions (distance-embedding tables, test aids). */
+int e3d_absmax_f32(const float* x, int64_t n, float* target, void* stream);
 
 /* Fused attention, head dim 64 ("edge aggregation" of the north star):
  *   S = (Q K^T + R) / sqrt(64) + (1 - key_mask) * -10000;  out = softmax(S) V
@@ -105,6 +116,10 @@ int64_t e3d_gemm_skinny_workspace_bytes(int M, int N, int K);
 int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                               int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
                               int64_t workspace_bytes, void* stream);
+/* ... with the |out| maximum of e3d_gemm_bias_act_f32_split_ex (``out_absmax`` may be NULL; act = none when given). */
+int e3d_gemm_skinny_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
+                                 int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
+                                 int64_t workspace_bytes, float* out_absmax, void* stream);
 /* Diagnostic switch (A/B timing, tools/lab/skinny_ab.py): the K-slicing plan of the kernels above -- waves per CU the
  * plan aims for (times 2; default 3 = 1.5 per CU) and the shortest K slice (default 96).  Query the workspace size AFTER
  * changing the plan.  Results differ between plans only by fp32 summation order. */
@@ -135,9 +150,12 @@ int e3d_gemm_general_select(int form);
 float e3d_attn_rescale_tau(float tau);
 
 /* Process-wide switch of the split attention kernels (default 1): stop the key sweep after the tile
- * holding the last valid key of the item.  Trailing all-padding tiles contribute exp(-10000 - m) = 0.0f
- * exactly, so results are bit-identical; 0 restores the dense sweep (timing comparisons).  Returns the
- * previous setting. */
+ * holding the last valid key of the item WHEN the call's element bounds (q_absmax / k_absmax / e_absmax of
+ * e3d_relkey_attn_fwd_split_ex) prove that trailing all-padding tiles contribute exp(s - 10000 - m) = 0.0f exactly --
+ * the reference masks additively (structure_model/model.py:226-231), so that holds only while the scores of a row
+ * spread over less than ~9900: 16 qa (ka + ea) < 9890.  Results are then bit-identical to the dense sweep; calls
+ * without bounds, or whose bounds do not prove it, always run the dense sweep.  0 = dense sweep for every call
+ * (timing comparisons).  Returns the previous setting. */
 int e3d_attn_skip_padded_tiles(int enable);
 
 /* out[M,H] = LayerNorm_eps(x[M,H] (+ residual[M,H])) * gamma + beta
@@ -277,13 +295,18 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
  * aligned, or NULL) receives the fragment-order bf16 hi/lo planes of dist_emb that the cooperative kernel
  * reads; with NULL (and a dist_emb) the per-wave kernel serves the call instead -- the library never
  * allocates.  ``e_scratch_ready`` != 0: the scratch still holds the planes written by an earlier call with the
- * same dist_emb values and Lk (constant weights: inference) -- the 5-us pre-pass is skipped. */
+ * same dist_emb values and Lk (constant weights: inference) -- the 5-us pre-pass is skipped.
+ * ``q_absmax`` / ``k_absmax`` / ``e_absmax`` (device, one float each, or NULL): upper bounds of |element| over the
+ * call's Q rows, K rows (INCLUDING padded positions) and the distance table (required with dist_emb when the other
+ * two are given) -- as left by e3d_gemm_bias_act_f32_split_ex / e3d_absmax_f32.  They only decide whether all-padding
+ * key tiles may be skipped (see e3d_attn_skip_padded_tiles); NULL = never skip.  Read on the device: no host sync. */
 int64_t e3d_attn_scratch_bytes(int Lk);
 int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                  int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                  const float* dist_emb, int P, const float* key_mask, float* out,
                                  float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
-                                 uint64_t drop_seed, void* e_scratch, int e_scratch_ready, void* stream);
+                                 uint64_t drop_seed, void* e_scratch, int e_scratch_ready, const float* q_absmax,
+                                 const float* k_absmax, const float* e_absmax, void* stream);
 
 /* e3d_relkey_attn_bwd for a forward that used (drop_p, drop_seed). */
 int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,

@@ -378,16 +378,36 @@ def test_config5_joint_chain_128_pockets_x128(pkg, hip, capsys):
     assert rel_err(logits, want) < TOL
 
 
-# ------------------------------------------------------------------------------------ bf16x3 margin (item 1b)
+# ------------------------------------------------------------------------------------ arithmetic margins
+def _oracle_fp64(sd, cfg, t, x_t, pk):
+    """The oracle in fp64 -- except the Fourier features, whose fp32 argument rounding (t * W * 2 pi at ~1e5 rad) is part
+    of the reference arithmetic -- as the ground truth the arithmetics are ranked against."""
+    sd64 = {k: v.double() for k, v in sd.items()}
+    orig = ostr.fourier_projection
+    ostr.fourier_projection = lambda s_, p_, tt: orig(sd, p_, tt).double()
+    try:
+        return ostr.forward(sd64, cfg, t, x_t.double(), pk["ligand_attn_mask"].double(), pk["receptor_seq"].double(),
+                            pk["receptor_angles"].double(), pk["receptor_attn_mask"].double())
+    finally:
+        ostr.fourier_projection = orig
+
+
 @pytest.mark.parametrize("regime,scale", [("random-init", 1.0), ("weights x2, gamma 0.5-2", 2.0), ("weights x4, gamma 0.5-2", 4.0)])
 def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, capsys):
     """Every arithmetic's distance from the 1e-4 contract at the bench's sequence length, 12+12 layers, in three
     weight regimes, reported element-wise (|d| / max(|ref|, 1e-3 rms): 99.9th percentile and max) beside the max-norm
-    figure the other tests assert on.  Asserted at random init.  The scaled regimes (attention logits x4 / x16:
-    saturating softmax rows) are ill-conditioned for ANY fp32 implementation -- measured on MI355X, max-norm vs the
-    CPU oracle: exact-fp32 MFMA 1.6e-4 (x2) / 9.7e-4 (x4), bf16x6 8e-5 / 0.47, bf16x3 8e-4 / 0.47 -- so they are
-    reported, not asserted: they say how far the 1e-4 contract itself can be trusted and that every split arithmetic
-    tracks the fp32 rounding error of the model by a constant factor (bf16x3 ~8x, f16x3 and bf16x6 ~1x)."""
+    figure the other tests assert on.
+
+    The scaled regimes sharpen the softmax rows (attention logits x4 / x16) and are ill-conditioned for ANY fp32
+    implementation: the CPU oracle in fp32 is itself ~3e-5..8e-5 (x2) / ~4e-4..7e-4 (x4, depending on the thread count's
+    summation order) away from the same oracle in fp64 (tools/lab/margin_cpu.py).  They are therefore ranked against the fp64 oracle, and asserted RELATIVE to the exact
+    fp32 MFMA kernels: the fp32-grade split arithmetics (f16x3, bf16x6) must stay within a small factor of the f32
+    figure -- x2: <= 2x, x4: <= 10x (measured on MI355X, vs fp64: x2 f32 1.5e-4, f16x3 8.0e-5, bf16x6 1.2e-4,
+    bf16x3 6.5e-4; x4 f32 8.0e-4, f16x3 5.5e-4, bf16x6 2.6e-3, bf16x3 0.12 -- at x4 the first encoder layer sees
+    activations of ~5000 and logits of ~1e7, where a 2^-17 product error is an absolute logit error of ~100).  (Round 2 reported 0.47 for every split arithmetic at x4 and called it
+    ill-conditioning; it was a defect -- the attention kernels skipped all-padding key tiles although the first encoder
+    layer's |q|, |k| ~ 7000 put padded keys above the -10000 mask, tools/lab/margin_bisect.py -- fixed by the
+    element-bound guard of e3d_relkey_attn_fwd_split_ex.)"""
     from test_structure_gpu import build
     L, B = 256, 2
     model, sd = build(pkg, FULL_STRUCT, L, seed=71)
@@ -398,21 +418,31 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
     d = to_dev(pk)
     x_t = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=gen(74)))
     t = torch.tensor([999, 3])
-    want = ostr.forward(sd, {"num_heads": 12, "max_pos": L}, t, x_t, pk["ligand_attn_mask"], pk["receptor_seq"],
-                        pk["receptor_angles"], pk["receptor_attn_mask"])
+    cfg = {"num_heads": 12, "max_pos": L}
+    want = ostr.forward(sd, cfg, t, x_t, pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"],
+                        pk["receptor_attn_mask"])
+    want64 = _oracle_fp64(sd, cfg, t, x_t, pk)
     m = pk["ligand_attn_mask"].bool()
-    rows = {}
+    rows = {"cpu-f32": (rel_err(want[m], want64[m]),) * 2 + elementwise_err(want[m], want64[m])}
     for mode in ("bf16x3", "f16x3", "bf16x6", "f32"):
         with pkg.ops.arithmetic(mode, respect_env=False), torch.no_grad():
             got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"],
                         d["receptor_attn_mask"]).cpu()
         assert torch.isfinite(got).all()
-        rows[mode] = (rel_err(got[m], want[m]),) + elementwise_err(got[m], want[m])
+        rows[mode] = (rel_err(got[m], want[m]), rel_err(got[m], want64[m])) + elementwise_err(got[m], want64[m])
     with capsys.disabled():
-        for mode, (mx, p999, emax) in rows.items():
-            print(f"\n[margin, {regime}, L=256 12+12, {mode}] max-norm {mx:.2e} | element-wise p99.9 {p999:.2e} max {emax:.2e}")
+        for mode, (mx, mx64, p999, emax) in rows.items():
+            print(f"\n[margin, {regime}, L=256 12+12, {mode}] max-norm vs fp32 oracle {mx:.2e}, vs fp64 oracle {mx64:.2e} | "
+                  f"element-wise (fp64) p99.9 {p999:.2e} max {emax:.2e}")
+    f32 = max(rows["f32"][1], rows["cpu-f32"][1])      # what an exact-fp32 implementation achieves here (GPU or CPU)
     if scale == 1.0:
         assert rows["bf16x3"][0] < TOL and rows["bf16x6"][0] < TOL and rows["f32"][0] < TOL and rows["f16x3"][0] < TOL
         # element-wise, floor 1e-3 rms: outputs 1000x below the rms carry the same ABSOLUTE error as the large ones, so
         # the percentile sits ~10-20x above the max-norm figure in every arithmetic (fp32 itself: 4e-5 vs 3e-6)
-        assert rows["bf16x3"][1] < 2e-3 and rows["bf16x6"][1] < 2e-4
+        assert rows["bf16x3"][2] < 2e-3 and rows["bf16x6"][2] < 2e-4
+        assert rows["f16x3"][1] < 3 * f32 and rows["bf16x6"][1] < 3 * f32
+    elif scale == 2.0:
+        assert rows["f16x3"][1] < 2 * f32 and rows["bf16x6"][1] < 2 * f32, rows
+        assert rows["bf16x3"][1] < 30 * f32, rows
+    else:
+        assert rows["f16x3"][1] < 10 * f32 and rows["bf16x6"][1] < 10 * f32, rows

@@ -152,8 +152,8 @@ def test_attention_fully_padded_item_matches_reference_semantics(pkg, hip):
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16x6", "f16x3"])
 def test_attention_padded_tile_skipping_is_bit_exact(pkg, hip, mode):
     """Stopping the key sweep after the last valid key's tile must not change a single bit
-    (trailing padding tiles contribute exp(-10000 - m) == 0), incl. masks with holes and an
-    all-padding item (which must keep the dense sweep)."""
+    (trailing padding tiles contribute exp(s - 10000 - m) == 0 while the element bounds prove the score spread small),
+    incl. masks with holes and an all-padding item (which must keep the dense sweep)."""
     B, nh, L, P = 4, 2, 256, 256
     H = nh * 64
     qkv = (torch.randn(B * L, 3 * H, generator=g(1)) * 1.5).to(DEV)
@@ -165,16 +165,143 @@ def test_attention_padded_tile_skipping_is_bit_exact(pkg, hip, mode):
     mask[2, :] = 1
     # item 3: no valid key at all
     mask = mask.to(DEV)
+    bound = pkg.ops.absmax(qkv)
+    assert float(bound) == float(qkv.abs().max())
     outs = []
     for enable in (1, 0):
         prev = hip.e3d_attn_skip_padded_tiles(enable)
         try:
             outs.append(pkg.ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask,
-                                          dist_emb=E, max_pos=P, want_lse=True, mode=mode))
+                                          dist_emb=E, max_pos=P, want_lse=True, mode=mode, bounds=(bound, bound)))
         finally:
             hip.e3d_attn_skip_padded_tiles(prev)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("L", [64, 256])     # per-wave kernel / cooperative kernel
+def test_attention_skips_padded_tiles_only_when_the_bounds_prove_it_exact(pkg, hip, mode, L):
+    """The skip is engaged exactly when 16 qa (ka + ea) < 9890 (include/e3d_hip.h).  Probe: V rows of the all-padding key
+    tiles are NaN -- the dense sweep multiplies them by P == 0 and returns NaN, the skipping sweep never reads them."""
+    B, nh, P = 2, 2, L
+    H = nh * 64
+    qkv = torch.randn(B * L, 3 * H, generator=g(3))
+    E = torch.randn(2 * P - 1, 64, generator=g(4)).to(DEV)
+    mask = torch.zeros(B, L)
+    mask[0, :20] = 1
+    mask[1, :L] = 1
+    small = pkg.ops.absmax(qkv.to(DEV))
+    qkv = qkv.view(B, L, 3 * H)
+    qkv[0, 32:, 2 * H:] = float("nan")
+    qkv = qkv.view(B * L, 3 * H).to(DEV)
+    big = torch.full((1,), 1.0e3, device=DEV)
+    nan = torch.full((1,), float("nan"), device=DEV)
+    run = lambda b: pkg.ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),  # noqa: E731
+                                      dist_emb=E, max_pos=P, mode=mode, bounds=b)
+    assert torch.isfinite(run((small, small))).all()                 # proven small: padded tiles never read
+    for b in (None, (big, small), (small, big), (nan, small), (small, nan)):
+        out = run(b).view(B, L, H)
+        assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all(), b   # dense sweep of item 0
+
+
+def _attention_case(pkg, B, nh, L, scale, seed, lens):
+    """qkv (Q, K x ``scale``), distance table, mask and the fp64 statement of the reference semantics."""
+    H, P = nh * 64, L
+    qkv = torch.randn(B * L, 3 * H, generator=g(seed))
+    qkv[:, :2 * H] *= scale
+    E = torch.randn(2 * P - 1, 64, generator=g(seed + 1))
+    mask = (torch.arange(L)[None] < torch.tensor(lens)[:, None]).float()
+    split = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3).double()  # noqa: E731
+    q, k, v = split(qkv[:, :H]), split(qkv[:, H:2 * H]), split(qkv[:, 2 * H:])
+    ref = ref_attention(q, k, v, mask.double(), E.double(), P).permute(0, 2, 1, 3).reshape(B * L, H).float()
+    return qkv, E, mask, ref, (q, k, v)
+
+
+@pytest.mark.parametrize("L", [64, 256])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16x6", 2e-4), ("f16x3", 2e-4), ("bf16x3", 4e-3)])
+def test_attention_sharp_softmax_rows_match_fp64(pkg, hip, mode, tol, L):
+    """logits far beyond std 1 -- Q, K x16, scores of std ~256 (rows are all but one-hot), the regime
+    trained checkpoints move towards -- in every arithmetic against the fp64 statement, through the bounded call
+    (the skip decision is live: 16 qa (ka + ea) is ~1e5 here, so the kernels must run the dense sweep).  A score carries an
+    absolute error of ~|s| 2^-24 (fp32 grade) or ~|s| 2^-17 (bf16x3), which is the relative error of its probability."""
+    B, nh = 2, 3
+    H = nh * 64
+    qkv, E, mask, ref, _ = _attention_case(pkg, B, nh, L, 16.0, 11, [L, max(1, L // 5)])
+    d = qkv.to(DEV)
+    bound = pkg.ops.absmax(d[:, :2 * H].contiguous())
+    got = pkg.ops.attention(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV), dist_emb=E.to(DEV),
+                            max_pos=L, mode=mode, bounds=(bound, bound))
+    assert rel_err(got, ref) < tol, rel_err(got, ref)
+
+
+@pytest.mark.parametrize("L", [64, 256])
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3", "bf16x3"])
+def test_attention_padded_keys_reach_the_softmax_when_scores_exceed_the_mask(pkg, hip, mode, L):
+    """The reference's mask is ADDITIVE (-10000, structure_model/model.py:226-231): once scores spread over more than
+    that, padded keys win softmax rows.  Round 2's kernels skipped all-padding key tiles unconditionally and were 0.47
+    off the oracle in the weights-x4 regime of the margin test (first encoder layer: |q|, |k| ~ 7000); the skip is now
+    taken only when the element bounds prove it exact.  Construction: queries and PADDED keys share a direction u
+    (q.k / 8 ~ +8192), valid keys point the other way (~ -8192): after the mask the padded keys lead by ~6000, so every
+    row of item 0 attends to padding, as the reference would.  Small-integer operands: the products are exact in every
+    arithmetic, what is left is the scale / exponent / PV rounding."""
+    B, nh = 2, 2
+    H = nh * 64
+    lens = [L // 4, L]
+    u = torch.where(torch.rand(64, generator=g(31)) < 0.5, -1.0, 1.0)
+    noise = lambda seed, *shape, sd=8.0: torch.round(torch.randn(*shape, generator=g(seed)) * sd).clamp(-60, 60)  # noqa: E731
+    valid = (torch.arange(L)[None] < torch.tensor(lens)[:, None])                      # [B,L]
+    q = 32.0 * u + noise(34, B, L, nh, 64)
+    k = torch.where(valid[:, :, None, None], -32.0 * u, 32.0 * u) + noise(35, B, L, nh, 64)
+    v = torch.randn(B, L, nh, 64, generator=g(33))
+    qkv = torch.cat([q.reshape(B * L, H), k.reshape(B * L, H), v.reshape(B * L, H)], 1).contiguous()
+    E = noise(36, 2 * L - 1, 64, sd=2.0)
+    mask = valid.float()
+    sp = lambda x: x.permute(0, 2, 1, 3).double()  # noqa: E731
+    qd, kd, vd = sp(q), sp(k), sp(v)
+    ref = ref_attention(qd, kd, vd, mask.double(), E.double(), L).permute(0, 2, 1, 3).reshape(B * L, H).float()
+    hard = torch.softmax((qd @ kd.transpose(-1, -2) + obert.relkey_scores_literal(qd, E.double(), L)) / 8.0
+                         + torch.where(valid, 0.0, -float("inf"))[:, None, None, :].double(), -1) @ vd
+    hard = hard.permute(0, 2, 1, 3).reshape(B * L, H).float()
+    assert rel_err(hard, ref) > 0.1          # the case does exercise the additive-mask semantics
+    d = qkv.to(DEV)
+    bound = pkg.ops.absmax(d[:, :2 * H].contiguous())
+    got = pkg.ops.attention(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV), dist_emb=E.to(DEV),
+                            max_pos=L, mode=mode, bounds=(bound, bound))
+    assert rel_err(got, ref) < (5e-2 if mode == "bf16x3" else 2e-3), rel_err(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 768, 768), (512, 2304, 768), (2000, 768, 1024), (4096, 2304, 768), (5120, 2304, 768)])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6", "f16x3"])
+def test_gemm_reports_the_largest_output_magnitude(pkg, hip, M, N, K, mode):
+    """``absmax=``: every forward kernel form (skinny, 128x128 / 256x128 general, 256x256, persistent) raises the device
+    scalar to exactly max |out| -- and never lowers it."""
+    a = torch.randn(M, K, generator=g(M)).to(DEV)
+    w = (torch.randn(N, K, generator=g(N + 1)) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g(3)).to(DEV)
+    slot = torch.zeros(1, device=DEV)
+    out = pkg.ops.gemm(a, w, b, mode=mode, absmax=slot)
+    assert float(slot) == float(out.abs().max())
+    assert torch.equal(out, pkg.ops.gemm(a, w, b, mode=mode))        # same results with and without the report
+    slot.fill_(1.0e9)
+    pkg.ops.gemm(a, w, b, mode=mode, absmax=slot)
+    assert float(slot) == 1.0e9
+    a[M // 2, 3] = float("nan")
+    slot.zero_()
+    pkg.ops.gemm(a, w, b, mode=mode, absmax=slot)
+    assert math.isnan(float(slot))                                     # a NaN output reads as "no bound"
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-6), ("bf16x6", 2e-6), ("f16x3", 3e-6), ("bf16x3", 2e-5)])
+def test_gemm_large_activations(pkg, hip, mode, tol):
+    """activations x16 (and x256, the first encoder layer of the weights-x4 regime) -- the split
+    arithmetics are scale-free inside their range: same relative accuracy as at unit scale."""
+    a = torch.randn(777, 768, generator=g(1))
+    w = torch.randn(256, 768, generator=g(2)) / math.sqrt(768)
+    for scale in (16.0, 256.0):
+        ref = ((a * scale).double() @ w.double().t()).float()
+        got = pkg.ops.gemm((a * scale).to(DEV), w.to(DEV), None, mode=mode)
+        assert rel_err(got, ref) < tol, (scale, rel_err(got, ref))
 
 
 def test_attention_rejects_relkey_longer_than_table(pkg, hip):
