@@ -280,7 +280,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, absmax=None):
-        z = ops.gemm(x, weight, bias, ops.ACT_NONE, absmax=absmax)
+        z = ops.gemm(x, weight, bias, ops.ACT_NONE, absmax=absmax, prescale=False)   # the weight changes every step
         ctx.act = act
         ctx.save_for_backward(x, weight, z if act != ops.ACT_NONE else None)
         ctx.has_bias = bias is not None

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M, int N, int K,
                                                          int tiles_n, int k_slice, int to_slabs, float* __restrict__ slabs,
-                                                         float* __restrict__ absmax) {
+                                                         float* __restrict__ absmax, float out_scale) {
     typedef typename SV<E>::x8 X8;
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile % tiles_n;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = tm * 32 + mfma32_row(r, half);
-        float v = acc[r] + bv;
+        float v = fmaf(acc[r], out_scale, bv);
         if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
         if (ACT == E3D_ACT_SILU) v = silu(v);
         if (row < M) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void gemm_skinny_kernel(const float* __restrict
 template <int ACT>
 __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restrict__ slabs, int n_slices, int tiles_n,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int64_t ldc, int M, int N, float* __restrict__ absmax) {
+                                                            int64_t ldc, int M, int N, float* __restrict__ absmax, float out_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int c0 = blockIdx.y * 256 + 4 * lane;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
     if (c0 < N) {
         const float* p = slabs + ((int64_t)(row >> 5) * tiles_n + (c0 >> 5)) * n_slices * 1024 + slab_offset(row & 31, c0 & 31);
         f32x4 v = slab_sum(p, n_slices);
+        if (out_scale != 1.0f) v *= out_scale;      // (a power of two: exact)
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + c0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
 template <int V>
 __global__ __launch_bounds__(256) void skinny_finish_layernorm_kernel(
     const float* __restrict__ slabs, int n_slices, const float* __restrict__ bias, const float* __restrict__ res,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ out, int M) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ out, int M,
+    float out_scale) {
     constexpr int H = 256 * V, tiles_n = H / 32;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void skinny_finish_layernorm_kernel(
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int c0 = 4 * (64 * i + lane);
+        if (out_scale != 1.0f) r[i] *= out_scale;   // (a power of two: exact)
         if (bias) r[i] += *reinterpret_cast<const f32x4*>(bias + c0);
         if (res) r[i] += *reinterpret_cast<const f32x4*>(res + (int64_t)row * H + c0);
         g[i] = *reinterpret_cast<const f32x4*>(gamma + c0);
@@ -255,12 +258,12 @@ Plan make_plan(int M, int N, int K) {
 
 template <typename E>
 int launch_partials(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-                    int K, int act, const Plan& p, int to_slabs, float* slabs, float* absmax, hipStream_t s) {
+                    int K, int act, const Plan& p, int to_slabs, float* slabs, float* absmax, float out_scale, hipStream_t s) {
     const dim3 grid(p.tiles, p.slices), block(64);
 #define E3D_SKINNY_CASE(a)                                                                                              \
     case a:                                                                                                             \
         hipLaunchKernelGGL((gemm_skinny_kernel<a, E>), grid, block, 0, s, A, lda, W, bias, out, ldc, M, N, K, p.tiles_n, \
-                           p.k_slice, to_slabs, slabs, absmax);                                                                \
+                           p.k_slice, to_slabs, slabs, absmax, out_scale);                                                                \
         break
     switch (act) {
         E3D_SKINNY_CASE(E3D_ACT_NONE);
@@ -303,7 +306,7 @@ extern "C" int64_t e3d_gemm_skinny_workspace_bytes(int M, int N, int K) {
 
 extern "C" int e3d_gemm_skinny_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                                             int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
-                                            int64_t workspace_bytes, float* absmax, void* stream) {
+                                            int64_t workspace_bytes, float* absmax, float out_scale, void* stream) {
     if (check_common(A, lda, W, out, M, N, K, terms, workspace, workspace_bytes)) return -1;
     E3D_REQUIRE(!absmax || act == E3D_ACT_NONE, "gemm_skinny: out_absmax exists for act = none");
     E3D_REQUIRE(ldc >= N && ldc % 4 == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0),
@@ -313,15 +316,15 @@ extern "C" int e3d_gemm_skinny_f32_split_ex(const float* A, int64_t lda, const f
     float* slabs = reinterpret_cast<float*>(workspace);
     const int to_slabs = p.slices > 1;
     const int rc = terms == E3D_TERMS_F16X3
-                       ? launch_partials<_Float16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, s)
-                       : launch_partials<__bf16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, s);
+                       ? launch_partials<_Float16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, out_scale, s)
+                       : launch_partials<__bf16>(A, lda, W, bias, out, ldc, M, N, K, act, p, to_slabs, slabs, absmax, out_scale, s);
     if (rc) return rc;
     if (to_slabs) {
         const dim3 grid((M + 3) / 4, (N + 255) / 256), block(256);
         switch (act) {
-            case E3D_ACT_NONE: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_NONE>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
-            case E3D_ACT_GELU: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_GELU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
-            default: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_SILU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax); break;
+            case E3D_ACT_NONE: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_NONE>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax, out_scale); break;
+            case E3D_ACT_GELU: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_GELU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax, out_scale); break;
+            default: hipLaunchKernelGGL(skinny_finish_kernel<E3D_ACT_SILU>, grid, block, 0, s, slabs, p.slices, p.tiles_n, bias, out, ldc, M, N, absmax, out_scale); break;
         }
     }
     return e3d_launch_status("e3d_gemm_skinny_f32_split");
@@ -331,13 +334,14 @@ extern "C" int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const floa
                                          int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
                                          int64_t workspace_bytes, void* stream) {
     return e3d_gemm_skinny_f32_split_ex(A, lda, W, bias, out, ldc, M, N, K, act, terms, workspace, workspace_bytes, nullptr,
-                                        stream);
+                                        1.0f, stream);
 }
 
-extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
-                                                            const float* residual, const float* gamma, const float* beta,
-                                                            float eps, float* out, int M, int H, int K, int terms,
-                                                            void* workspace, int64_t workspace_bytes, void* stream) {
+extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias,
+                                                               const float* residual, const float* gamma, const float* beta,
+                                                               float eps, float* out, int M, int H, int K, int terms,
+                                                               void* workspace, int64_t workspace_bytes, float out_scale,
+                                                               void* stream) {
     if (check_common(A, lda, W, out, M, H, K, terms, workspace, workspace_bytes)) return -1;
     E3D_REQUIRE(gamma && beta, "gemm_skinny_residual_layernorm: null gamma / beta");
     E3D_REQUIRE(H == 256 || H == 512 || H == 768 || H == 1024, "gemm_skinny_residual_layernorm: H must be 256/512/768/1024 (H=%d)", H);
@@ -345,15 +349,23 @@ extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int6
     const Plan p = make_plan(M, H, K);
     float* slabs = reinterpret_cast<float*>(workspace);
     const int rc = terms == E3D_TERMS_F16X3
-                       ? launch_partials<_Float16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, s)
-                       : launch_partials<__bf16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, s);
+                       ? launch_partials<_Float16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, 1.0f, s)
+                       : launch_partials<__bf16>(A, lda, W, nullptr, out, H, M, H, K, E3D_ACT_NONE, p, 1, slabs, nullptr, 1.0f, s);
     if (rc) return rc;
     const dim3 grid((M + 3) / 4), block(256);
     switch (H) {
-        case 256: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<1>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M); break;
-        case 512: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<2>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M); break;
-        case 768: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<3>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M); break;
-        default: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<4>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M); break;
+        case 256: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<1>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M, out_scale); break;
+        case 512: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<2>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M, out_scale); break;
+        case 768: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<3>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M, out_scale); break;
+        default: hipLaunchKernelGGL(skinny_finish_layernorm_kernel<4>, grid, block, 0, s, slabs, p.slices, bias, residual, gamma, beta, eps, out, M, out_scale); break;
     }
     return e3d_launch_status("e3d_gemm_skinny_residual_layernorm_f32_split");
+}
+
+extern "C" int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int64_t lda, const float* W, const float* bias,
+                                                            const float* residual, const float* gamma, const float* beta,
+                                                            float eps, float* out, int M, int H, int K, int terms,
+                                                            void* workspace, int64_t workspace_bytes, void* stream) {
+    return e3d_gemm_skinny_residual_layernorm_f32_split_ex(A, lda, W, bias, residual, gamma, beta, eps, out, M, H, K, terms,
+                                                           workspace, workspace_bytes, 1.0f, stream);
 }

@@ -43,6 +43,11 @@ __device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// what the forward epilogues do besides bias + activation: ``absmax`` (may be null) is raised to the largest |out|
+// (e3d_common.h), ``scale`` multiplies the accumulator before the bias -- the inverse of the power of two a caller
+// scaled the weight by so that its fp16 terms sit in the normal range (include/e3d_hip.h, out_scale)
+struct Epi { float* absmax; float scale; };
+
 constexpr int BN = 128, BK = 32;
 #ifndef E3D_GEMM_FRAG_PREFETCH
 #define E3D_GEMM_FRAG_PREFETCH 1
@@ -173,7 +178,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
                                                 const float* __restrict__ bias, float* __restrict__ out, int64_t ldc,
                                                 int M, int N, int K_total, int tiles_m, int tiles_n, int k_chunk,
                                                 int bx, int by, int ny, float* __restrict__ colsum_out, int accumulate,
-                                                float* __restrict__ absmax = nullptr) {
+                                                float* __restrict__ absmax = nullptr, float out_scale = 1.0f) {
     constexpr int NBUF = NS == 2 ? 2 : 1;
     constexpr int BM = WM * 64, BN = WN * 32 * TN, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
@@ -332,7 +337,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + wr * 64 + m * 32 + mfma32_row(r, half);
-                float v = acc[m][n][r] + bv;
+                float v = fmaf(acc[m][n][r], out_scale, bv);   // (out_scale = 1: acc + bv, bit for bit)
                 if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                 if (ACT == E3D_ACT_SILU) v = silu(v);
                 if (row < M && col < N) {
@@ -372,11 +377,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
                                                          const float* __restrict__ bias,
                                                          float* __restrict__ out, int64_t ldc, int M,
                                                          int N, int K_total, int tiles_m, int tiles_n,
-                                                         int k_chunk, float* __restrict__ absmax) {
+                                                         int k_chunk, float* __restrict__ absmax, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
                                                         tiles_n, k_chunk, xcd_remap(blockIdx.x, tiles_m * tiles_n),
-                                                        blockIdx.y, gridDim.y, nullptr, 0, absmax);
+                                                        blockIdx.y, gridDim.y, nullptr, 0, absmax, out_scale);
 }
 
 // Weight gradients of up to 64 linear layers of ONE shape in one launch: problem p computes dW_p[N,K] = dz_p^T . x_p
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
                                                                         const float* __restrict__ bias,
                                                                         float* __restrict__ out, int64_t ldc,
                                                                         int M, int N, int K, int tiles_m,
-                                                                        int tiles_n, float* __restrict__ absmax) {
+                                                                        int tiles_n, float* __restrict__ absmax, float out_scale) {
     static_assert(!PIPE || NBUF == 2, "PIPE needs two LDS buffers");
     STAMP_K(0);   // kernel entry
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + wr * 128 + m * 32 + mfma32_row(r, half);
-                float v = acc[m][n][r] + bv;
+                float v = fmaf(acc[m][n][r], out_scale, bv);   // (out_scale = 1: acc + bv, bit for bit)
                 if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                 if (ACT == E3D_ACT_SILU) v = silu(v);
                 if (row < M) {
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                                                                  const float* __restrict__ W,
                                                                  const float* __restrict__ bias,
                                                                  float* __restrict__ out, int64_t ldc, int N, int K,
-                                                                 int tiles_m, int tiles_n, float* __restrict__ absmax) {
+                                                                 int tiles_m, int tiles_n, float* __restrict__ absmax, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NS = 2, T_BYTES = BT * ROW64, BUF_BYTES = 2 * NS * T_BYTES;
     constexpr int NI = 8;   // float4 items per thread and k-tile: 0..3 from A, 4..7 from W
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
                 float* o = out + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * ldc + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[m][n][r] + bv;
+                    float v = fmaf(acc[m][n][r], out_scale, bv);   // (out_scale = 1: acc + bv, bit for bit)
                     if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                     if (ACT == E3D_ACT_SILU) v = silu(v);
                     E3D_STORE_OUT(&o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc], v);
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __r
 
 template <int ACT, typename E>
 int launch256p(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-               int K, float* absmax, hipStream_t s) {
+               int K, Epi epi, hipStream_t s) {
     const int tiles_m = M / BT, tiles_n = N / BT;
     constexpr size_t lds = 2 * 2 * 2 * BT * ROW64;
     static std::atomic<uint64_t> lds_ok{0};
@@ -797,7 +802,7 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
     const int n_cu = e3d_cu_count();
     const int total = tiles_m * tiles_n;
     hipLaunchKernelGGL((gemm_split256p_kernel<ACT, E>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias,
-                       out, ldc, N, K, tiles_m, tiles_n, absmax);
+                       out, ldc, N, K, tiles_m, tiles_n, epi.absmax, epi.scale);
     return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
 }
 
@@ -807,20 +812,20 @@ int g_tile_pref = -1;  // E3D_GEMM_TILE (A/B runs): 0 = 256x128 (8 waves of 64x6
 
 template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE, typename E>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-              int K, float* absmax, hipStream_t s) {
+              int K, Epi epi, hipStream_t s) {
     constexpr int TM = WR * 128, TN = WC * 64;
     const int tiles_m = (M + TM - 1) / TM, tiles_n = N / TN;
     const size_t lds = (size_t)NBUF * NS * (TM + TN) * ROW64;
     static std::atomic<uint64_t> lds_ok{0};
     e3d_allow_lds(lds_ok, gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE, E>, lds);
     hipLaunchKernelGGL((gemm_split256_kernel<NS, ACT, WR, WC, NBUF, PIPE, E>), dim3(tiles_m * tiles_n), dim3(WR * WC * 64), lds, s,
-                       A, lda, W, bias, out, ldc, M, N, K, tiles_m, tiles_n, absmax);
+                       A, lda, W, bias, out, ldc, M, N, K, tiles_m, tiles_n, epi.absmax, epi.scale);
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
-                   int M, int N, int K, float* absmax, hipStream_t s);
+                   int M, int N, int K, Epi epi, hipStream_t s);
 
 // smallest number of 256x256 tiles for which the persistent kernel is chosen (E3D_GEMM_P_MIN, experiments)
 int p_min() {
@@ -834,7 +839,7 @@ int p_min() {
 
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, typename E>
 int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
-           int M, int N, int K, float* absmax, hipStream_t s) {
+           int M, int N, int K, Epi epi, hipStream_t s) {
     if (g_tile_pref < 0) {
         const char* e = getenv("E3D_GEMM_TILE");
         g_tile_pref = e ? atoi(e) : 4;
@@ -843,13 +848,13 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         if constexpr (NS == 2) {
             if (N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && K >= 2 * BK && lda < (1 << 22) &&
                 (int64_t)(M / BT) * (N / BT) >= p_min())
-                return launch256p<ACT, E>(A, lda, B, bias, out, ldc, M, N, K, absmax, s);
+                return launch256p<ACT, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
             if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
-                return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, absmax, s);
+                return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
         }
         if (N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
             (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
-            return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, absmax, s);
+            return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
     }
     // general kernel, three tile forms: 1 = 256x128 (8 waves, one workgroup per CU: 96 KB of LDS), 2 = 128x128 (4 waves,
     // two per CU), 3 = 128x128 on 8 waves (each 64x32; forward and input-gradient layouts of the 2-term kernels).  Both are bound by the latency of a workgroup's own k-step chain at these sizes, so the choice is a
@@ -877,16 +882,16 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         // 26.6 us at M = 4096, N = K = 768, bit-identical results; a 12-workgroup launch takes 23.5 us either way, so
         // the k-step's cost is proportional to its bytes, not a fixed barrier / latency term: here the fragment reads
         // (1 ds_read_b128 per MFMA at 64x32 per wave) cost as much LDS time as the MFMAs cost matrix-pipe time.)
-        if (form == 3) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 4, E, 1>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+        if (form == 3) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 4, E, 1>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     }
     if (form == 3) form = 2;
-    if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
-    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+    if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+    return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
 }
 
 template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
-                   int M, int N, int K, float* absmax, hipStream_t s) {
+                   int M, int N, int K, Epi epi, hipStream_t s) {
     constexpr int BM = WM * 64, BNt = WN * 32 * TN;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BNt - 1) / BNt;
     constexpr int NBUF = NS == 2 ? 2 : 1;
@@ -921,18 +926,18 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
     }
     hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>), dim3(tiles_m * tiles_n, splits),
                        dim3(WM * WN * 64), lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk,
-                       splits > 1 ? nullptr : absmax);
+                       splits > 1 ? nullptr : epi.absmax, epi.scale);
     return e3d_launch_status("e3d_gemm_f32_split");
 }
 
 template <int NS, typename E>
 int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, const float* B, int64_t ldb,
-             const float* bias, float* out, int64_t ldc, int M, int N, int K, float* absmax, hipStream_t s) {
+             const float* bias, float* out, int64_t ldc, int M, int N, int K, Epi epi, hipStream_t s) {
     if (!a_kmaj && !b_kmaj) {
         switch (act) {
-            case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
-            case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
-            case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+            case E3D_ACT_NONE: return launch<NS, E3D_ACT_NONE, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+            case E3D_ACT_GELU: return launch<NS, E3D_ACT_GELU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+            case E3D_ACT_SILU: return launch<NS, E3D_ACT_SILU, false, false, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
         }
         e3d_set_error("gemm_split: unknown activation %d", act);
         return -1;
@@ -942,9 +947,9 @@ int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, con
         return -1;
     }
     // K-major operand layouts (the training GEMMs) exist for the bf16 terms only
-    if (!a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, false, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
-    if (a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, true, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, nullptr, s);
-    return launch<NS, E3D_ACT_NONE, true, false, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+    if (!a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, false, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+    if (a_kmaj && b_kmaj) return launch<NS, E3D_ACT_NONE, true, true, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, Epi{nullptr, epi.scale}, s);
+    return launch<NS, E3D_ACT_NONE, true, false, __bf16>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
 }
 
 }  // namespace
@@ -977,7 +982,9 @@ extern "C" int e3d_gemm_general_select(int form) {
 
 static int gemm_split_general(const float* A, int64_t lda, int a_kmajor, const float* B, int64_t ldb, int b_kmajor,
                               const float* bias, float* out, int64_t ldc, int M, int N, int K, int act, int terms,
-                              float* absmax, void* stream) {
+                              float* absmax, float out_scale, void* stream) {
+    const Epi epi{absmax, out_scale};
+    E3D_REQUIRE(out_scale == 1.0f || !(a_kmajor && b_kmajor), "gemm_split: out_scale is not available for the split-K layout");
     E3D_REQUIRE(A && B && out, "gemm_split: null pointer");
     E3D_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_split: bad shape M=%d N=%d K=%d", M, N, K);
     E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "gemm_split: terms must be 3, 6 or 19 (got %d)", terms);
@@ -991,20 +998,20 @@ static int gemm_split_general(const float* A, int64_t lda, int a_kmajor, const f
     hipStream_t s = (hipStream_t)stream;
     E3D_REQUIRE(!absmax || (!(a_kmajor && b_kmajor) && act == E3D_ACT_NONE),
                 "gemm_split: out_absmax exists for act = none and not for the split-K (weight-gradient) layout");
-    if (terms == 3) return dispatch<2, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+    if (terms == 3) return dispatch<2, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     if (terms == E3D_TERMS_F16X3) {
         // fp16 terms exist for the forward layout; a K-major operand (training GEMMs) runs the fp32-grade bf16x6 form
-        if (!a_kmajor && !b_kmajor) return dispatch<2, _Float16>(act, false, false, A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
-        return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+        if (!a_kmajor && !b_kmajor) return dispatch<2, _Float16>(act, false, false, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+        return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     }
-    return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, absmax, s);
+    return dispatch<3, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
 }
 
 extern "C" int e3d_gemm_f32_split_general(const float* A, int64_t lda, int a_kmajor, const float* B,
                                           int64_t ldb, int b_kmajor, const float* bias, float* out,
                                           int64_t ldc, int M, int N, int K, int act, int terms,
                                           void* stream) {
-    return gemm_split_general(A, lda, a_kmajor, B, ldb, b_kmajor, bias, out, ldc, M, N, K, act, terms, nullptr, stream);
+    return gemm_split_general(A, lda, a_kmajor, B, ldb, b_kmajor, bias, out, ldc, M, N, K, act, terms, nullptr, 1.0f, stream);
 }
 
 extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const float* const* x, float* const* dw,
@@ -1043,12 +1050,12 @@ extern "C" int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const fl
                                            const float* bias, float* out, int64_t ldc, int M,
                                            int N, int K, int act, int terms, void* stream) {
     E3D_REQUIRE(N % BN == 0, "gemm_split: need N%%128==0 (N=%d)", N);
-    return gemm_split_general(A, lda, 0, W, (int64_t)K, 0, bias, out, ldc, M, N, K, act, terms, nullptr, stream);
+    return gemm_split_general(A, lda, 0, W, (int64_t)K, 0, bias, out, ldc, M, N, K, act, terms, nullptr, 1.0f, stream);
 }
 
 extern "C" int e3d_gemm_bias_act_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                                               int64_t ldc, int M, int N, int K, int act, int terms, float* out_absmax,
-                                              void* stream) {
+                                              float out_scale, void* stream) {
     E3D_REQUIRE(N % BN == 0, "gemm_split: need N%%128==0 (N=%d)", N);
-    return gemm_split_general(A, lda, 0, W, (int64_t)K, 0, bias, out, ldc, M, N, K, act, terms, out_absmax, stream);
+    return gemm_split_general(A, lda, 0, W, (int64_t)K, 0, bias, out, ldc, M, N, K, act, terms, out_absmax, out_scale, stream);
 }

@@ -18,7 +18,7 @@ _SIGNATURES = {
     "e3d_last_error": (c_char_p, []),
     "e3d_gemm_bias_act_f32": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "e3d_gemm_bias_act_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P]),
-    "e3d_gemm_bias_act_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "e3d_gemm_bias_act_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P]),
     "e3d_absmax_f32": (c_int, [_P, c_int64, _P, _P]),
     "e3d_relkey_attn_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64,
                                     _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -26,10 +26,12 @@ _SIGNATURES = {
                                           _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "e3d_gemm_skinny_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "e3d_gemm_skinny_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
-    "e3d_gemm_skinny_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P]),
+    "e3d_gemm_skinny_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, c_float, _P]),
     "e3d_gemm_skinny_plan_select": (None, [c_int, c_int]),
     "e3d_gemm_skinny_residual_layernorm_f32_split": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int,
                                                      c_int, _P, c_int64, _P]),
+    "e3d_gemm_skinny_residual_layernorm_f32_split_ex": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_float, _P, c_int, c_int, c_int,
+                                                        c_int, _P, c_int64, c_float, _P]),
     "e3d_attn_skip_padded_tiles": (c_int, [c_int]),
     "e3d_gemm_kernel_select": (c_int, [c_int]),
     "e3d_gemm_general_select": (c_int, [c_int]),

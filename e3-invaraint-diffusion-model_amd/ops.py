@@ -1,6 +1,8 @@
 """Tensor-level wrappers over the C-ABI: allocate outputs with torch (device memory + stream
 plumbing only) and enqueue the HIP kernels on torch's current stream."""
+import math
 import os
+import warnings
 
 import torch
 
@@ -182,6 +184,44 @@ def set_gemm_mode(mode):
     return prev
 
 
+# f16x3 weights: two fp16 terms carry 22 bits only while BOTH are normal numbers -- an element below 2^-3 = 0.125
+# already has its low term in the fp16 subnormals (absolute floor 2^-25), and nn.Linear weights are ~0.02-0.05.  Each
+# weight is therefore multiplied by a power of two (exact) that puts its largest |element| in [2^11, 2^12) -- elements
+# down to 2^-15 of the largest keep 22 bits, the largest is 16x below the fp16 maximum, a weight of ANY magnitude is safe
+# -- and the kernels multiply the accumulator by the inverse power (exact) before the bias (``out_scale`` of the *_ex
+# entry points).  Scaled copies are cached on the weight tensor (keyed like every derived-weight cache); building one
+# reads max |w| back to the host, once per weight and version.  Activations are not scaled: the path's GEMM inputs are
+# LayerNorm / GELU / softmax outputs, and an activation beyond 65504 gives inf / NaN -- loudly.
+F16_WEIGHT_EXP = 12
+_f16_warned = False
+
+
+def f16_weight(weight):
+    """(weight * 2^k, 2^-k): the f16x3 operand of ``weight`` and the accumulator scale that undoes it."""
+    global _f16_warned
+    ent = getattr(weight, "_e3d_f16w", None)
+    key = weight_key(weight)
+    if ent is not None and ent[0] == key:
+        return ent[1], ent[2]
+    if torch.cuda.is_current_stream_capturing():     # no host read-back inside a capture (callers warm up first)
+        return weight, 1.0
+    with torch.no_grad():
+        amax = float(weight.detach().abs().max())
+        if not math.isfinite(amax) or amax == 0.0:
+            if not math.isfinite(amax) and not _f16_warned:
+                _f16_warned = True
+                warnings.warn("f16x3: a weight holds inf / NaN -- used as it is (the outputs will say so)")
+            scaled, inv = weight.detach(), 1.0
+        else:
+            k = max(-120, min(120, F16_WEIGHT_EXP - math.frexp(amax)[1]))
+            scaled, inv = (weight.detach() * (2.0 ** k)).contiguous(), 2.0 ** -k
+    try:
+        weight._e3d_f16w = (key, scaled, inv)
+    except AttributeError:
+        pass
+    return scaled, inv
+
+
 # Small launches (one to ~16 pockets per step) go to the "skinny" kernels (csrc/gemm_skinny.hip: K cut across
 # workgroups so the whole chip streams the weight, partial tiles in a workspace, a second launch finishes the rows).  The
 # workspace must not be shared by launches that may run concurrently: one per (device, stream), grown on demand and kept.
@@ -209,10 +249,12 @@ def _skinny_ok(terms, M, N, K, a):
             and -(-M // 32) * (N // 32) <= SKINNY_MAX_TILES)
 
 
-def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None):
+def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None, prescale=True):
     """out[M,N] = act(a[M,K] @ weight[N,K]^T + bias).  ``a`` may be a row-strided 2-D view.  ``absmax`` (1-element
     device tensor, act = none): raised to the largest |out| by the kernel's epilogue (split arithmetics; the exact-f32
-    kernels have no use for it -- their attention twin never skips key tiles)."""
+    kernels have no use for it -- their attention twin never skips key tiles).  ``prescale`` (f16x3 only): run the
+    product on the cached power-of-two-scaled copy of the weight (``f16_weight``); False for weights that change every
+    step (the training forward)."""
     _chk(a, "gemm.a"); _chk(weight, "gemm.weight"); _chk(bias, "gemm.bias")
     assert a.dim() == 2 and a.stride(1) == 1 and weight.is_contiguous()
     M, K = a.shape
@@ -225,19 +267,22 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None):
     if absmax is not None:
         _chk(absmax, "gemm.absmax")
         assert act == ACT_NONE and absmax.numel() == 1
+    scale = 1.0
+    if terms == 19 and prescale:
+        weight, scale = f16_weight(weight)
     with _timed("gemm", (M, N, K, act)):
         if _skinny_ok(terms, M, N, K, a) and out.stride(0) % 4 == 0:
             ws = _skinny_workspace(a.device, M, N, K)
             hip.check(hip.lib().e3d_gemm_skinny_f32_split_ex(_p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0),
-                                                             M, N, K, act, terms, _p(ws), ws.numel(), _p(absmax), _stream()),
+                                                             M, N, K, act, terms, _p(ws), ws.numel(), _p(absmax), scale, _stream()),
                       "e3d_gemm_skinny_f32_split_ex")
         elif terms == 0:
             hip.check(hip.lib().e3d_gemm_bias_act_f32(_p(a), a.stride(0), _p(weight), _p(bias), _p(out),
                                                       out.stride(0), M, N, K, act, _stream()), "e3d_gemm_bias_act_f32")
         else:
             hip.check(hip.lib().e3d_gemm_bias_act_f32_split_ex(
-                _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _p(absmax), _stream()),
-                "e3d_gemm_bias_act_f32_split_ex")
+                _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _p(absmax), scale,
+                _stream()), "e3d_gemm_bias_act_f32_split_ex")
     return out
 
 
@@ -378,10 +423,13 @@ def linear_residual_layernorm(a, weight, bias, residual, gamma, beta, eps, mode=
     assert weight.is_contiguous() and weight.shape[1] == K and (residual is None or (residual.is_contiguous() and residual.shape == (M, H)))
     out = torch.empty((M, H), device=a.device, dtype=torch.float32)
     ws = _skinny_workspace(a.device, M, H, K)
+    scale = 1.0
+    if terms == 19:
+        weight, scale = f16_weight(weight)
     with _timed("gemm_layernorm", (M, H, K)):
-        hip.check(hip.lib().e3d_gemm_skinny_residual_layernorm_f32_split(
+        hip.check(hip.lib().e3d_gemm_skinny_residual_layernorm_f32_split_ex(
             _p(a), a.stride(0), _p(weight), _p(bias), _p(residual), _p(gamma), _p(beta), eps, _p(out), M, H, K, terms,
-            _p(ws), ws.numel(), _stream()), "e3d_gemm_skinny_residual_layernorm_f32_split")
+            _p(ws), ws.numel(), scale, _stream()), "e3d_gemm_skinny_residual_layernorm_f32_split_ex")
     return out
 
 def adaln_gate(x, y, mod, branch, rows_per_cond):

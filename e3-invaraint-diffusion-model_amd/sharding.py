@@ -95,7 +95,11 @@ class GradientAverager:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._flat, self._handles, self._pending, self._bound, self._touched = {}, {}, None, False, set()
-        if overlap and hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+        # the view / overlap path of ``prepare`` needs to hear about every gradient (hooks, or ``mark_ready``):
+        # without hooks it would not know which parameters backward touched, so ``prepare`` then leaves the
+        # gradients alone and ``average`` takes the copying path
+        self._hooked = bool(overlap) and hasattr(torch.Tensor, "register_post_accumulate_grad_hook")
+        if self._hooked:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -115,7 +119,7 @@ class GradientAverager:
         bucket's flat buffer (autograd then accumulates in place: no flatten / unflatten copies), and a bucket
         goes on the wire -- asynchronously, overlapping the rest of the backward pass -- the moment its last
         gradient has been accumulated.  Without this call ``average`` still works (copying path)."""
-        if not self._active():
+        if not self._active() or not self._hooked:
             return
         for i, bucket in enumerate(self.buckets):
             flat = self._buffer(i)
@@ -137,8 +141,8 @@ class GradientAverager:
                 p.grad = None
 
     def _on_grad(self, p):
-        if not self._bound:
-            return
+        if not self._bound or id(p) in self._touched:    # once per parameter and step: a weight may be reported both by
+            return                                       # its hook and by ``mark_ready`` (mixed deferred / direct uses)
         self._touched.add(id(p))
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1

@@ -64,10 +64,15 @@ int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W, con
  * NULL) is raised atomically to max(*out_absmax, max |out[m][n]|) -- never lowered, so the caller zeroes it when it wants
  * a fresh figure; a NaN / inf output leaves a NaN / inf there.  act must be E3D_ACT_NONE when out_absmax is given.
  * Purpose: the bounds of e3d_relkey_attn_fwd_split_ex (below), which let the attention kernels skip all-padding key
- * tiles only when that is provably exact.  Costs two integer VALU operations per output element. */
+ * tiles only when that is provably exact.  Costs two integer VALU operations per output element.
+ * ``out_scale``: out = act(out_scale * (A W^T) + bias).  For terms = 19 (f16x3) a caller hands in W * 2^k (exact) with k
+ * chosen so that max |W| 2^k sits near 2^12, and out_scale = 2^-k (exact): both fp16 terms of every weight element down
+ * to 2^-15 of the largest are then normal numbers (22 bits), instead of an absolute 2^-25 floor below 2^-14 -- a
+ * uniformly tiny weight (|w| ~ 1e-6) goes from ~2e-2 to fp32-grade relative error -- and a weight beyond the fp16 range
+ * cannot overflow.  1.0f = the plain product (bit-identical to e3d_gemm_bias_act_f32_split). */
 int e3d_gemm_bias_act_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                                    int64_t ldc, int M, int N, int K, int act, int terms, float* out_absmax,
-                                   void* stream);
+                                   float out_scale, void* stream);
 /* target = max(target, max_i |x[i]|), same conventions (distance-embedding tables, test aids). */
 int e3d_absmax_f32(const float* x, int64_t n, float* target, void* stream);
 
@@ -116,10 +121,11 @@ int64_t e3d_gemm_skinny_workspace_bytes(int M, int N, int K);
 int e3d_gemm_skinny_f32_split(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                               int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
                               int64_t workspace_bytes, void* stream);
-/* ... with the |out| maximum of e3d_gemm_bias_act_f32_split_ex (``out_absmax`` may be NULL; act = none when given). */
+/* ... with the |out| maximum and the accumulator scale of e3d_gemm_bias_act_f32_split_ex (``out_absmax`` may be NULL;
+ * act = none when given; out_scale = 1.0f: the plain product). */
 int e3d_gemm_skinny_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias, float* out,
                                  int64_t ldc, int M, int N, int K, int act, int terms, void* workspace,
-                                 int64_t workspace_bytes, float* out_absmax, void* stream);
+                                 int64_t workspace_bytes, float* out_absmax, float out_scale, void* stream);
 /* Diagnostic switch (A/B timing, tools/lab/skinny_ab.py): the K-slicing plan of the kernels above -- waves per CU the
  * plan aims for (times 2; default 3 = 1.5 per CU) and the shortest K slice (default 96).  Query the workspace size AFTER
  * changing the plan.  Results differ between plans only by fp32 summation order. */
@@ -132,6 +138,12 @@ int e3d_gemm_skinny_residual_layernorm_f32_split(const float* A, int64_t lda, co
                                                  const float* residual, const float* gamma, const float* beta, float eps,
                                                  float* out, int M, int H, int K, int terms, void* workspace,
                                                  int64_t workspace_bytes, void* stream);
+/* ... with out_scale: LayerNorm(out_scale * (A W^T) + bias + residual). */
+int e3d_gemm_skinny_residual_layernorm_f32_split_ex(const float* A, int64_t lda, const float* W, const float* bias,
+                                                    const float* residual, const float* gamma, const float* beta,
+                                                    float eps, float* out, int M, int H, int K, int terms,
+                                                    void* workspace, int64_t workspace_bytes, float out_scale,
+                                                    void* stream);
 
 /* Diagnostic switch (A/B timing, tools/bench_kernels.py): which kernel form serves large-M forward launches of
  * e3d_gemm_bias_act_f32_split with terms = 3 -- 4 = persistent 256x256 (default), 3 = 256x256 with interleaved

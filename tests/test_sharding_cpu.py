@@ -79,6 +79,28 @@ def _worker(rank, world, port, q):
     assert torch.allclose(model["a"].weight.grad, sum(both) / world)
     assert torch.allclose(model["b"].bias.grad, torch.full_like(model["b"].bias, 1.5))
     assert model["unused"].weight.grad is None
+    # a parameter reported twice in one step (hook AND mark_ready: a weight with a deferred and a direct use) counts once
+    for p in model.parameters():
+        p.grad = None
+    avg.prepare()
+    model["b"](model["a"](x)).sum().backward()
+    for p in used:
+        avg.mark_ready(p)
+    assert all(n >= 0 for n in avg._pending)
+    avg.average()
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
+    # ---- overlap=False installs no hooks, so prepare() must not bind the view path -- average()
+    # then takes the copying path and EVERY used parameter keeps its (averaged) gradient
+    for p in model.parameters():
+        p.grad = None
+    plain = S.GradientAverager(model.parameters(), bucket_bytes=32, overlap=False)
+    plain.prepare()
+    assert not plain._bound
+    model["b"](model["a"](x)).sum().backward()
+    plain.average()
+    assert all(p.grad is not None for p in used)
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
+    assert model["unused"].weight.grad is None
     w0 = [torch.zeros_like(model["a"].weight) for _ in range(world)]
     torch.distributed.all_gather(w0, model["a"].weight.data)
     assert torch.equal(w0[0], w0[1])
