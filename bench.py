@@ -112,9 +112,34 @@ def cpu_baseline(L, seed):
             times.append(time.perf_counter() - t0)
             print(f"[cpu_baseline] step {i}: {times[-1]:.2f} s on {cores} threads", file=sys.stderr, flush=True)
     med = sorted(times[warm:])[len(times[warm:]) // 2]
-    return {"value": B / med, "unit": "pocket-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement of the reference incl. relative_key), structure model 12+12 layers, "
-                      f"B={B} x L={L} pockets, {warm} warm-up + {timed} timed reverse steps, median"}
+    out = {"value": B / med, "unit": "pocket-steps/s", "cores": cores, "kind": "port",
+           "sample": f"oracle (CPU restatement of the reference incl. relative_key), structure model 12+12 layers, "
+                     f"B={B} x L={L} pockets, {warm} warm-up + {timed} timed reverse steps, median"}
+    # BASELINE configs[0] end to end: ONE 64-residue pocket (ligand 12), T = 50, the whole
+    # p_sample_loop as structure_model/sample.py:101-144 runs it (encoder recomputed every step, as the reference does)
+    L1, T1 = 64, 50
+    common = dict(hidden_size=H, num_attention_heads=NH, intermediate_size=INTER, num_hidden_layers=LAYERS,
+                  max_position_embeddings=L1)
+    m = ConditionalBertForDiffusionBase(BertConfig(**common),
+                                        BertConfig(**common, is_decoder=True, add_cross_attention=True), 8)
+    sd1 = seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
+    del m
+    cfg1 = {"num_heads": NH, "max_pos": L1}
+    pk1 = synthetic_pockets(1, L1, seed=seed, lig_range=(12, 12), rec_range=(64, 64))
+    fn1 = lambda t, xx, lm, rs, ra, rm: ostr.forward(sd1, cfg1, t, xx, lm, rs, ra, rm)  # noqa: E731
+    betas1 = ostr.cosine_beta_schedule(T1)
+    x1 = ostr.modulo_with_wrapped_range(torch.randn(1, L1, 8))
+    with torch.no_grad():
+        for rep in range(2):          # first chain = warm-up
+            t0 = time.perf_counter()
+            ostr.p_sample_loop(fn1, pk1["ligand_attn_mask"], x1, pk1["receptor_seq"], pk1["receptor_attn_mask"],
+                               pk1["receptor_angles"], T1, betas1)
+            chain_s = time.perf_counter() - t0
+            print(f"[cpu_baseline] config 1 chain {rep}: {chain_s:.2f} s on {cores} threads", file=sys.stderr, flush=True)
+    out["config1"] = {"value": T1 / chain_s, "unit": "pocket-steps/s", "chain_s": chain_s, "cores": cores, "kind": "port",
+                      "sample": f"the same oracle, B=1 x L={L1} (ligand 12, pocket 64), T={T1} reverse steps end to end "
+                                "(second of two chains)"}
+    return out
 
 
 def launch_workers(n):
@@ -186,6 +211,10 @@ def main():
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra training-step timings")
+    ap.add_argument("--no-joint-leg", action="store_true", help="skip the joint structure -> sequence chain (config 5 share)")
+    ap.add_argument("--train-ddp-batch", type=int, default=64, help="per-rank batch of the train_ddp leg (N > 1)")
+    ap.add_argument("--train-ddp-seq-len", type=int, default=128)
+    ap.add_argument("--train-ddp-layers", type=int, default=6)
     ap.add_argument("--gemm-mode", default=os.environ.get("E3D_GEMM_MODE", "f16x3"),
                     choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="GEMM arithmetic of the headline value (see DESIGN.md section 3)")
@@ -359,12 +388,13 @@ def main():
     dom_bytes = sum(4.0 * (m[0] * m[2] + m[1] * m[2] + m[0] * m[1] + m[1]) for _, m in dom) / max(1, len(dom))
 
     if rank == 0:
-        traffic = gemm_traffic = None
+        traffic = gemm_traffic = traffic_source = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             tdict = json.load(open(tj))
             traffic = tdict.get(f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch")
             gemm_traffic = tdict.get(f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch")
+            traffic_source = tdict.get("source")
         a_tf = attn_flops(B, L) / (attn_ms * 1e-3) / 1e12
         gemm_peak = {"f32": PEAK_F32_MATRIX_TFLOPS, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6, "f16x3": 2500.0 / 3}[args.gemm_mode]
         a_gb = attn_bytes(B, L) / (attn_ms * 1e-3) / 1e9
@@ -375,14 +405,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "f32 storage and accumulation, bf16x3 products",
+                      "bf16x6": "f32 storage and accumulation, bf16x6 products (fp32 grade)",
+                      "f16x3": "f32 storage and accumulation, f16x3 products (fp32 grade)"}[args.gemm_mode],
+            "data": "synthetic",
             "gemm_mode": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                           "bf16x3": "fp32 operands split into 2 bf16 terms, 3 cross products on the bf16 MFMA, fp32 accumulate",
                           "bf16x6": "fp32 operands split into 3 bf16 terms, 6 cross products on the bf16 MFMA, fp32 accumulate "
                                     "(fp32-grade)",
                           "f16x3": "fp32 operands split into 2 fp16 terms (11 + 11 bits), 3 cross products on the fp16 MFMA, fp32 "
-                                   "accumulate (fp32-grade: 4.9e-6 end to end at L=256 vs 3.2e-6 for the exact fp32 MFMA path; "
-                                   "operands must lie inside the fp16 range)"}[args.gemm_mode],
+                                   "accumulate (fp32-grade: 3.8e-6 end to end at L=256 vs 2.6e-6 for the exact fp32 MFMA path, both against "
+                                   "the fp64 oracle; weights pre-scaled by an exact power of two so that both terms are normal "
+                                   "fp16 numbers, activations must lie inside the fp16 range -- beyond it the outputs are inf/NaN)"}[args.gemm_mode],
             "value_by_gemm_mode": {m: B * world / by_mode[m] for m in modes},
             "config": {"workload": f"structure_model sampling step, {B} x {L}-residue pockets per GPU, "
                                    "12+12 layers x 768, T=1000 schedule, encoder recomputed every step (as the reference)",
@@ -406,7 +440,7 @@ def main():
                 "achieved": a_gb if t_hbm > t_mfma else a_tf,
                 "peak": PEAK_HBM_GBPS if t_hbm > t_mfma else gemm_peak,
                 "unit": "GB/s" if t_hbm > t_mfma else "TFLOP/s",
-                "frac": max(t_hbm, t_mfma) / attn_ms, "traffic": traffic,
+                "frac": max(t_hbm, t_mfma) / attn_ms, "traffic": traffic, "traffic_source": traffic_source,
                 "peak_note": "MFMA peak: fp32 157.3 TFLOP/s for f32; bf16 / fp16 dense 2500 / cross products for the split modes",
                 "avg_launch_ms": attn_ms, "launches_per_step": n_attn, "dense_key_sweep": True,
                 "algorithmic_TFLOPs": a_tf, "mfma_frac": a_tf / gemm_peak,
@@ -420,6 +454,11 @@ def main():
                                    f"all {len(dom)} launches of one step (M={B * L}; N, K in gemm_shapes)",
                          "bound": "mfma", "achieved": dom_flops / (dom_ms * 1e-3) / 1e12, "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": dom_flops / (dom_ms * 1e-3) / 1e12 / gemm_peak, "traffic": gemm_traffic,
+                         "traffic_source": traffic_source,
+                         "traffic_note": None if not gemm_traffic else
+                         f"{gemm_traffic / dom_bytes:.2f}x the algorithmic bytes: the A row block is re-fetched by the N tiles "
+                         "of its row (served by the memory-side cache; priced at ~7 % of the launch by the fixed-operand "
+                         "ablation, profiles/README.md)",
                          "avg_launch_ms": dom_ms, "launches_per_step": len(dom),
                          "algorithmic_flops_per_launch": dom_flops, "algorithmic_bytes_per_launch": dom_bytes,
                          "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes; traffic = HBM "
@@ -446,8 +485,32 @@ def main():
             import bench_single
             # BASELINE configs[0] on the GPU: ONE 64-residue pocket, 50 reverse steps (latency, not throughput)
             out["single_pocket"] = bench_single.run(seq_len=64, batch=1, steps=50)
+            if not args.no_joint_leg:
+                # BASELINE configs[4], one GPU's share: 128 pockets x L=128, structure T=1000 -> hand-over on the device ->
+                # sequence T=50 (sequence_model/sample_by_generated_angles.py:196-278); the reference's padded frames,
+                # then the frames trimmed to the longest ligand / pocket (valid positions unchanged)
+                import bench_joint
+                out["joint"] = {"padded": bench_joint.run(128, 128, 1000, 50, trim=False, device=str(device)),
+                                "trimmed": bench_joint.run(128, 128, 1000, 50, trim=True, device=str(device)),
+                                "note": "config 5 = 1024 pockets over 8 GPUs: this is one rank's 128 (pocket-sharded, no "
+                                        "collective until the final gather)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, seed=0)
+    if world > 1 and not args.headline_only and not args.no_train_leg:
+        # extra key for N > 1 (never the headline): BASELINE config 4 -- the sequence model's data-parallel training
+        # step, per-rank batch 64, gradients averaged over the ranks (RCCL all-reduce of the bucket views, overlapped
+        # with the deferred weight-gradient launches).  Every rank runs it; rank 0 reports the max-over-ranks time.
+        del model
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train
+        ddp = bench_train.run("sequence", batch=args.train_ddp_batch, seq_len=args.train_ddp_seq_len, steps=5, warmup=2,
+                              device=str(device), ddp=True, layers=args.train_ddp_layers, seed=rank)
+        if rank == 0:
+            out["train_ddp"] = dict(ddp, note="sequence model (reference sequence_model/train_model.py:93-104 under DDP), "
+                                              "forward + loss + backward + gradient all-reduce / world + clip + AdamW; "
+                                              "ms_per_step = max over ranks")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -73,3 +73,29 @@ def test_on_device_forward_noising_matches_dataset_path(pkg, hip):
     assert modulo_with_wrapped_range(out["noised_ligand_angle"].cpu() - want).abs().max() < 2e-6
     auto = noise_batch_on_device(x0.cuda(), tab)
     assert auto["timestep"].shape == (5, 1) and auto["known_noise"].abs().max() <= 3.1416
+
+
+def test_bench_two_rank_rehearsal_reports_the_data_parallel_training_leg():
+    """`python bench.py --gpus 2` with E3D_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo for the collectives -- the control
+    path of the multi-GPU line on a one-GPU box (never a measurement).  Rank 0's single JSON line must carry the headline
+    keys AND the ``train_ddp`` extra key (BASELINE config 4, the sequence model's DDP step with the
+    overlapped GradientAverager), and the ranks must still hold identical weights after the timed steps (asserted inside
+    tools/bench_train.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["E3D_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--seq-len", "64", "--only-default-mode", "--train-ddp-batch", "4",
+                        "--train-ddp-seq-len", "64", "--train-ddp-layers", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    ddp = out["train_ddp"]
+    assert ddp["ranks"] == 2 and ddp["global_batch"] == 8 and ddp["backend"] == "gloo" and ddp["ms_per_step"] > 0
+    assert ddp["model"] == "sequence" and ddp["buckets"] >= 1 and "train" not in out

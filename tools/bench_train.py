@@ -23,11 +23,17 @@ from e3diff_amd.bert import BertConfig  # noqa: E402
 DEV = "cuda:0"
 
 
-def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2):
+def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2, device=DEV, ddp=False, layers=None,
+        seed=0):
     """One GPU's training step of BASELINE config 2 (structure, B=32) / config 4 (sequence, B=64): forward + loss +
-    backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict."""
+    backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict.
+    ``ddp``: the step of ``training.fit`` under an initialised process group (BASELINE config 4: one rank per GPU,
+    per-rank batch 64) -- weights broadcast from rank 0, gradients as views of the all-reduce buckets, the buckets sent
+    (RCCL; gloo in rehearsals) while the deferred weight-gradient launches of the later layers still run; timed between
+    barriers, max over ranks by the caller."""
+    DEV = device   # noqa: N806 (shadows the module default)
     L = seq_len
-    layers = 12 if model_name == "structure" else 6
+    layers = layers or (12 if model_name == "structure" else 6)
     B = batch or (32 if model_name == "structure" else 64)
     c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=layers,
              max_position_embeddings=L, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
@@ -47,7 +53,13 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
     model = model.train().to(DEV)
     optim = model.configure_optimizers()["optimizer"]
     params = [p for p in model.parameters() if p.requires_grad]
-    pk = {k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=0, with_ligand_seq=True).items() if torch.is_tensor(v)}
+    pk = {k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=seed, with_ligand_seq=True).items() if torch.is_tensor(v)}
+    averager = None
+    if ddp:
+        import torch.distributed as dist
+        from e3diff_amd import sharding
+        sharding.broadcast_parameters(model, src=0)
+        averager = sharding.GradientAverager(model.parameters())
 
     def step():
         if model_name == "structure":
@@ -56,11 +68,16 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
             batch_ = pk
         loss = model.training_step(batch_)
         optim.zero_grad(set_to_none=True)
+        if averager is not None:
+            averager.prepare()
         if pkg.training.DEFER_WEIGHT_GRADS:        # as training.fit does: weight gradients grouped at the end of backward
-            with pkg.autograd.deferred_weight_grads():
+            on_param = averager.mark_ready if (averager is not None and averager._active()) else None
+            with pkg.autograd.deferred_weight_grads(on_param=on_param):
                 loss.backward()
         else:
             loss.backward()
+        if averager is not None:
+            averager.average()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         optim.step()
         return loss
@@ -70,13 +87,31 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
+        if ddp and dist.is_initialized():
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
         torch.cuda.synchronize()
+        if ddp and dist.is_initialized():
+            dist.barrier()
         dt = (time.perf_counter() - t0) / steps
+    if ddp and dist.is_initialized():
+        from e3diff_amd import sharding
+        dt = sharding.max_over_ranks(dt)
+        w = torch.cat([p.detach().reshape(-1)[:64] for p in params]).double().sum()
+        ws = [torch.zeros_like(w) for _ in range(dist.get_world_size())]
+        if dist.get_backend() != "nccl":
+            w = w.cpu()
+            ws = [t.cpu() for t in ws]
+        dist.all_gather(ws, w)
+        assert all(float(t) == float(ws[0]) for t in ws), "ranks diverged"
     return {"model": model_name, "batch": B, "seq_len": L, "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
             "arithmetic": mode, "dropout": dropout, "ms_per_step": dt * 1e3, "samples_per_s": B / dt,
+            **({"ranks": dist.get_world_size(), "global_batch": B * dist.get_world_size(),
+                "global_samples_per_s": B * dist.get_world_size() / dt, "backend": dist.get_backend(),
+                "gradient_MB_per_step": sum(p.numel() for p in params) * 4 / 1e6,
+                "buckets": len(averager.buckets)} if (ddp and dist.is_initialized()) else {}),
             "loss": float(loss.detach()), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
 
 
