@@ -383,7 +383,7 @@ def main():
     dom = [(ev0.elapsed_time(ev1), m) for n, ev0, ev1, m in trace
            if n == "gemm" and (len(m) < 4 or m[3] == 0) and m[0] % 256 == 0 and m[1] % 256 == 0
            and (m[0] // 256) * (m[1] // 256) >= 256]
-    dom_ms = sum(t for t, _ in dom) / max(1, len(dom))
+    dom_ms = sum(t for t, _ in dom) / max(1, len(dom)) or float("nan")   # (no large-M launch at rehearsal sizes)
     dom_flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in dom) / max(1, len(dom))
     dom_bytes = sum(4.0 * (m[0] * m[2] + m[1] * m[2] + m[0] * m[1] + m[1]) for _, m in dom) / max(1, len(dom))
 
@@ -455,7 +455,7 @@ def main():
                          "bound": "mfma", "achieved": dom_flops / (dom_ms * 1e-3) / 1e12, "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": dom_flops / (dom_ms * 1e-3) / 1e12 / gemm_peak, "traffic": gemm_traffic,
                          "traffic_source": traffic_source,
-                         "traffic_note": None if not gemm_traffic else
+                         "traffic_note": None if not (gemm_traffic and dom_bytes) else
                          f"{gemm_traffic / dom_bytes:.2f}x the algorithmic bytes: the A row block is re-fetched by the N tiles "
                          "of its row (served by the memory-side cache; priced at ~7 % of the launch by the fixed-operand "
                          "ablation, profiles/README.md)",
