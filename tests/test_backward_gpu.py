@@ -212,14 +212,47 @@ def test_cross_attention_backward_rectangular(pkg, hip, Fm):
     sp = lambda x, L: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3)  # noqa: E731
     ref = ref_attention(sp(qr, Lq), sp(kr[:, :H], Lk), sp(kr[:, H:], Lk), mask.double(), None, 0)
     ref.permute(0, 2, 1, 3).reshape(B * Lq, H).backward(go.double())
-    prev = pkg.ops.set_attn_mode("bf16x6")
+    for mode, tol in (("bf16x6", 2e-5), ("bf16x3", 1e-4)):    # bf16x3: the fused recomputing kernel (attn_bwd_coop.hip)
+        prev = pkg.ops.set_attn_mode(mode)
+        try:
+            qd, kd = leaf(q, DEV), leaf(kv, DEV)
+            Fm.attention(qd, kd, B, nh, Lq, Lk, key_mask=mask.to(DEV)).backward(go.to(DEV))
+        finally:
+            pkg.ops.set_attn_mode(prev)
+        assert rel_err(qd.grad, qr.grad.float()) < tol, mode
+        assert rel_err(kd.grad[:, :H], kr.grad[:, :H].float()) < tol, mode
+        assert rel_err(kd.grad[:, H:], kr.grad[:, H:].float()) < tol, mode
+
+
+@pytest.mark.parametrize("B,nh,L", [(3, 2, 128), (2, 3, 96), (2, 1, 33)])
+def test_fused_attention_backward_matches_the_two_launch_kernels(pkg, hip, Fm, B, nh, L, monkeypatch):
+    """attn_bwd_coop.hip (one launch, P / dS recomputed on chip, operands split once per (item, head)) against the
+    two-launch bf16x3 kernels it replaces (P / dS through HBM): same arithmetic class, so the two agree far inside the
+    1e-4 budget -- every gradient incl. the distance table, masks with padded tails, L not a multiple of 32."""
+    import subprocess, sys, json   # noqa: E401 (the switch is read once per process: the old path runs in a child)
+    H, P = nh * 64, L
+    qkv = torch.randn(B * L, 3 * H, generator=g(L))
+    E = torch.randn(2 * P - 1, 64, generator=g(P + 1))
+    lens = torch.randint(1, L + 1, (B,), generator=g(5))
+    lens[0] = L
+    mask = (torch.arange(L)[None] < lens[:, None]).float()
+    go = torch.randn(B * L, H, generator=g(9))
+    prev = pkg.ops.set_attn_mode("bf16x3")
     try:
-        qd, kd = leaf(q, DEV), leaf(kv, DEV)
-        Fm.attention(qd, kd, B, nh, Lq, Lk, key_mask=mask.to(DEV)).backward(go.to(DEV))
+        qd, Ed = leaf(qkv, DEV), leaf(E, DEV)
+        Fm.attention(qd, None, B, nh, L, L, key_mask=mask.to(DEV), dist_emb=Ed, max_pos=P).backward(go.to(DEV))
     finally:
         pkg.ops.set_attn_mode(prev)
-    assert rel_err(qd.grad, qr.grad.float()) < 2e-5
-    assert rel_err(kd.grad, kr.grad.float()) < 2e-5
+    qr, Er = leaf(qkv, dtype=torch.double), leaf(E, dtype=torch.double)
+    sp = lambda x: x.reshape(B, L, nh, 64).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ref_attention(sp(qr[:, :H]), sp(qr[:, H:2 * H]), sp(qr[:, 2 * H:]), mask.double(), Er, P)
+    ref.permute(0, 2, 1, 3).reshape(B * L, H).backward(go.double())
+    for part, name in ((slice(0, H), "dq"), (slice(H, 2 * H), "dk"), (slice(2 * H, 3 * H), "dv")):
+        assert rel_err(qd.grad[:, part], qr.grad[:, part].float()) < 5e-5, name
+    assert rel_err(Ed.grad, Er.grad.float()) < 5e-5
+    # rows of padded queries / keys get exact zeros where the reference does
+    valid = mask.bool().reshape(-1)
+    assert float(qd.grad[~valid][:, H:].abs().max() if (~valid).any() else 0.0) < 1e-30
 
 
 def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
