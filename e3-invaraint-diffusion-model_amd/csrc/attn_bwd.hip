@@ -374,7 +374,7 @@ extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs
         E3D_REQUIRE(((uintptr_t)workspace % 16) == 0, "attn_bwd: workspace must be 16-byte aligned");
         const int rc = e3d_attn_bwd_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout,
                                                 dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, workspace, part, B, nh, Lq,
-                                                Lk, s);
+                                                Lk, drop, drop_p > 0.f, s);
         if (rc) return rc;
     } else if (terms == 3) {   // bf16x3 arithmetic (attn_bwd_split.hip); 0 and 6 keep the fp32 MFMA kernels below
         const int rc = e3d_attn_bwd_split_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse,

@@ -3,7 +3,7 @@
 // probabilities P and dS never leave the chip (attn_bwd_split.hip materialises both in HBM between its two launches
 // and re-splits every operand row per (query tile, key tile) pair: 2600 VALU instructions per pair against 99 MFMAs).
 //
-// One workgroup of 4 waves per (batch item, head), Lq, Lk <= 128 (every training configuration of the reference:
+// One workgroup of 4 waves per (batch item, head, phase), Lq, Lk <= 128 (every training configuration of the reference:
 // max_seq_len = 128).  Operands are split into bf16 hi / lo planes ONCE per workgroup and parked in LDS images that
 // serve both access patterns of the MFMA operands:
 //   * "row fragments"  (lane = token, 8 consecutive head dims): products that contract over the head dim
@@ -215,14 +215,17 @@ __global__ __launch_bounds__(256) void e_planes_kernel(const float* __restrict__
 // blockIdx.y = phase: 0 = dK / dV workgroups, 1 = dQ / dE workgroups.  The two halves share nothing but their inputs, so
 // they run as separate workgroups of one launch (grid = B x heads x 2: 768 workgroups of ~half the length instead of
 // 384 -- at one workgroup per CU a 384-workgroup grid leaves half the chip idle in its second round)
-template <bool RELKEY>
+// DROP: the forward applied dropout multipliers m (0 or 1 / (1 - p), regenerated here from the seed) to the normalised
+// probabilities: O = (P o m) V  =>  dP = (V dO^T) o m, dS = P (dP - delta) / 8 with delta = rowsum(dO o O) unchanged,
+// dV = (P o m)^T dO.
+template <bool RELKEY, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs, int64_t k_rs,
     const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const bf16x8* __restrict__ e_row, const bf16x8* __restrict__ e_tr,
     int P, const float* __restrict__ key_mask, const float* __restrict__ dout, const float* __restrict__ outp,
     const float* __restrict__ lse, float* __restrict__ dq, int64_t dq_bs, int64_t dq_rs, float* __restrict__ dk,
     int64_t dk_bs, int64_t dk_rs, float* __restrict__ dv, int64_t dv_bs, int64_t dv_rs, float* __restrict__ dE_part, int nh,
-    int Lq, int Lk) {
+    int Lq, int Lk, E3dDrop drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* img0 = smem_raw;               // phase A: Q      phase B: K
     unsigned char* img1 = smem_raw + IMG_B;       // phase A: dO     phase B: V
@@ -316,10 +319,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
-                    const bool ok = key_ok && (32 * qt + 8 * g + 4 * half + j) < Lq;
+                    const int qg = 32 * qt + 8 * g + 4 * half + j;
+                    const bool ok = key_ok && qg < Lq;
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], S_SCALE, bias_k) - l4[j]) : 0.f;
-                    s[r] = p;
-                    ds[r] = p * (dp[r] - d4[j]) * 0.125f;
+                    float mult = 1.0f;
+                    if (DROP) {   // one hash per 4 consecutive keys of a query row: this lane's key is element key & 3
+                        float m4[4];
+                        e3d_drop_mult4(drop, e3d_attn_drop_idx4(bh, Lq, Lk, min(qg, Lq - 1), min(key, Lk - 1) & ~3), m4);
+                        const int e = key & 3;
+                        mult = e == 0 ? m4[0] : (e == 1 ? m4[1] : (e == 2 ? m4[2] : m4[3]));
+                    }
+                    s[r] = p * mult;
+                    ds[r] = p * (dp[r] * mult - d4[j]) * 0.125f;
                 }
             }
             // dV^T += dO^T P,  dK^T += Q^T dS: B = the accumulator tiles as they stand (k = query rows rho(8 st + j, half))
@@ -404,12 +415,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(kbias + r0 + 8 * g + 4 * half);
+                float m4[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) e3d_drop_mult4(drop, e3d_attn_drop_idx4(bh, Lq, Lk, min(qrow, Lq - 1), r0 + 8 * g + 4 * half), m4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * g + j;
                     const bool ok = q_ok && (r0 + 8 * g + 4 * half + j) < Lk;
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], S_SCALE, b4[j]) - lse_q) : 0.f;
-                    ds[r] = p * (dp[r] - delta_q) * 0.125f;
+                    ds[r] = p * (dp[r] * m4[j] - delta_q) * 0.125f;
                 }
             }
             // dQ^T += K^T dS^T
@@ -506,7 +519,8 @@ bool e3d_attn_bwd_coop_supported(int Lq, int Lk, bool dropping) {
         const char* e = getenv("E3D_ATTN_BWD_COOP");
         on = e ? atoi(e) : 1;
     }
-    return on && !dropping && Lq <= 32 * MAX_TILES && Lk <= 32 * MAX_TILES;
+    (void)dropping;   // (dropout is regenerated inside the fused kernel)
+    return on && Lq <= 32 * MAX_TILES && Lk <= 32 * MAX_TILES;
 }
 
 // The fused backward, bf16x3 (arguments validated by e3d_relkey_attn_bwd_ex; ``e_scratch``: 16-byte aligned,
@@ -516,23 +530,27 @@ int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const f
                              const float* key_mask, const float* out, const float* lse, const float* dout, float* dq,
                              int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs, float* dv,
                              int64_t dv_bs, int64_t dv_rs, void* e_scratch, float* part, int B, int nh, int Lq, int Lk,
-                             hipStream_t s) {
+                             E3dDrop drop, bool dropping, hipStream_t s) {
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
     bf16x8* e_row = reinterpret_cast<bf16x8*>(e_scratch);
     bf16x8* e_tr = e_row ? e_row + n_items : nullptr;
     if (dist_emb)
         hipLaunchKernelGGL(e_planes_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, e_row, e_tr, P, J0, n_items);
-    static std::atomic<uint64_t> ok_rk{0}, ok_plain{0};
+    static std::atomic<uint64_t> ok[4];
+#define E3D_BWD_COOP(RK, DR)                                                                                               \
+    do {                                                                                                                   \
+        e3d_allow_lds(ok[2 * RK + DR], attn_bwd_coop_kernel<RK, DR>, LDS_BYTES);                                           \
+        hipLaunchKernelGGL((attn_bwd_coop_kernel<RK, DR>), dim3(B * nh, 2), dim3(256), LDS_BYTES, s, q, q_bs, q_rs, k, k_bs, \
+                           k_rs, v, v_bs, v_rs, e_row, e_tr, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, dk, dk_bs,      \
+                           dk_rs, dv, dv_bs, dv_rs, part, nh, Lq, Lk, drop);                                               \
+    } while (0)
     if (dist_emb) {
-        e3d_allow_lds(ok_rk, attn_bwd_coop_kernel<true>, LDS_BYTES);
-        hipLaunchKernelGGL(attn_bwd_coop_kernel<true>, dim3(B * nh, 2), dim3(256), LDS_BYTES, s, q, q_bs, q_rs, k, k_bs, k_rs, v,
-                           v_bs, v_rs, e_row, e_tr, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs,
-                           dv_rs, part, nh, Lq, Lk);
+        if (dropping) E3D_BWD_COOP(true, true);
+        else E3D_BWD_COOP(true, false);
     } else {
-        e3d_allow_lds(ok_plain, attn_bwd_coop_kernel<false>, LDS_BYTES);
-        hipLaunchKernelGGL(attn_bwd_coop_kernel<false>, dim3(B * nh, 2), dim3(256), LDS_BYTES, s, q, q_bs, q_rs, k, k_bs, k_rs, v,
-                           v_bs, v_rs, e_row, e_tr, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs,
-                           dv_rs, part, nh, Lq, Lk);
+        if (dropping) E3D_BWD_COOP(false, true);
+        else E3D_BWD_COOP(false, false);
     }
+#undef E3D_BWD_COOP
     return e3d_launch_status("e3d_relkey_attn_bwd (fused, bf16x3)");
 }
