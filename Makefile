@@ -1,6 +1,6 @@
 # Convenience targets (the driver calls __graft_entry__.build()/smoke(), pytest and bench.py directly).
 PY ?= python
-TAG ?= r02b
+TAG ?= r03
 
 build:            ## hipcc --offload-arch=gfx950 -> e3-invaraint-diffusion-model_amd/libe3d_hip.so
 	$(PY) -c "import __graft_entry__ as g; g.build()"

@@ -40,8 +40,15 @@ class deferred_weight_grads:
     ``stages`` slices, last layers first, so that the first buckets travel while the later slices compute."""
     active = None
 
+    # The queued (dz, x) pairs stay alive until the flush -- without the queue autograd frees each pair as backward
+    # proceeds.  At BASELINE config 2 (4096 tokens, 12 + 12 layers) that is ~2.6 GB of extra peak memory, growing linearly
+    # with B x L; when the queued bytes pass this budget the queue is flushed early (what is queued so far is grouped
+    # and computed, backward continues with an empty queue).  E3D_DEFER_WGRAD_MAX_GB, default 16 (of 288 GB of HBM).
+    MAX_BYTES = int(float(os.environ.get("E3D_DEFER_WGRAD_MAX_GB", "16")) * 2 ** 30)
+
     def __init__(self, on_param=None, stages=3):
         self.pending, self.on_param, self.stages = [], on_param, max(1, int(stages))
+        self.queued_bytes, self.early_flushes, self._seen_ptrs, self._early_touched = 0, 0, set(), {}
 
     def __enter__(self):
         assert deferred_weight_grads.active is None, "deferred_weight_grads blocks do not nest"
@@ -56,6 +63,20 @@ class deferred_weight_grads:
 
     def add(self, dz, x, weight, bias):
         self.pending.append((dz, x, weight, bias))
+        for t in (dz, x):      # (the row blocks of a packed weight share one dz / x: count a storage once)
+            if t is None:
+                continue
+            key = t.untyped_storage().data_ptr()
+            if key not in self._seen_ptrs:
+                self._seen_ptrs.add(key)
+                self.queued_bytes += t.untyped_storage().nbytes()
+        if self.queued_bytes > self.MAX_BYTES:
+            # early flush: compute what is queued, but report nothing to a listening averager yet -- a weight used
+            # twice in the forward pass (sequence model: ligand_feature_emb) may still receive its second contribution
+            self.early_flushes += 1
+            pending, self.pending = self.pending, []
+            self.queued_bytes, self._seen_ptrs = 0, set()
+            self._early_touched.update(self._flush_slice(pending))
 
     MIN_TILES = int(os.environ.get("E3D_WGRAD_MIN_TILES", "96"))   # 256x128 output tiles a grouped launch needs (of 256 CUs; sweep in DESIGN.md)
 
@@ -81,6 +102,13 @@ class deferred_weight_grads:
 
     def flush(self):
         pending, self.pending = self.pending, []
+        self.queued_bytes, self._seen_ptrs = 0, set()
+        early, self._early_touched = self._early_touched, {}
+        if self.on_param is not None:     # parameters finished by an early flush and not queued again: complete now
+            still = {id(t) for item in pending for t in item[2:] if t is not None}
+            for pid, p_ in early.items():
+                if pid not in still:
+                    self.on_param(p_)
         if not pending:
             return
         # With a gradient averager listening (on_param), the queue is worked off in ``stages`` slices, last layers
@@ -130,6 +158,16 @@ class deferred_weight_grads:
                         if has_bias:
                             touched[id(b)] = b
                     continue
+                # a layer whose weight already holds a gradient while its bias does not (or the reverse: a bias shared
+                # with a layer outside the queue, a gradient set by hand) cannot ride in a grouped launch -- one
+                # accumulate bit per problem covers both outputs -- so it takes the per-layer path
+                mixed = [it for it in items if has_bias and (it[2].grad is None) != (it[3].grad is None)]
+                for dz, x, w, b in mixed:
+                    self._single(dz, x, w, b, N, K, M)
+                    touched[id(w)] = w
+                    touched[id(b)] = b
+                if mixed:
+                    items = [it for it in items if not any(it is m for m in mixed)]
                 for lo in range(0, len(items), 64):
                     chunk = items[lo:lo + 64]
                     n = len(chunk)
@@ -140,7 +178,7 @@ class deferred_weight_grads:
                         a_dz[i], a_x[i], a_dw[i] = dz.data_ptr(), x.data_ptr(), gw.data_ptr()
                         if has_bias:
                             gb, acc_b = self._grad_buffer(b)
-                            assert acc_b == acc_w, "weight and bias of a layer must both (not) hold a gradient already"
+                            assert acc_b == acc_w      # (mixed layers were taken out above)
                             a_db[i] = gb.data_ptr()
                         bits |= int(acc_w) << i
                     hip.check(lib.e3d_gemm_wgrad_grouped_f32_split(a_dz, a_x, a_dw, a_db if has_bias else None, bits, n, ldz,

@@ -401,3 +401,37 @@ def test_transposed_weight_registry_refreshes_all_stale_weights_together(pkg, hi
     assert t2 is got[-1] and torch.equal(t2, packed2.detach().t())
     for w, t in zip(ws, got):
         assert torch.equal(AG._transposed_weight(w), w.detach().t())
+
+
+def test_deferred_weight_gradient_queue_flushes_early_past_its_memory_budget(pkg, hip, Fm, monkeypatch):
+    """the queue keeps every (dz, x) pair alive until the end of backward.  Past E3D_DEFER_WGRAD_MAX_GB it
+    computes what is queued and goes on -- same gradients, every parameter reported to a listener exactly once and only
+    after its last contribution (a weight used twice must not be reported by the early flush)."""
+    from e3diff_amd.autograd import deferred_weight_grads
+    torch.manual_seed(0)
+    lin = [torch.nn.Linear(256, 256).to(DEV) for _ in range(3)]
+    x = torch.randn(512, 256, device=DEV)
+
+    def loss():
+        h = Fm.linear(x, lin[0].weight, lin[0].bias)
+        h = Fm.linear(h, lin[1].weight, lin[1].bias)
+        h = Fm.linear(h, lin[0].weight, lin[0].bias)      # lin[0] twice
+        return Fm.linear(h, lin[2].weight, lin[2].bias).square().mean()
+
+    def grads(budget_bytes):
+        for m in lin:
+            m.zero_grad(set_to_none=True)
+        monkeypatch.setattr(deferred_weight_grads, "MAX_BYTES", budget_bytes)
+        reported = []
+        with pkg.ops.arithmetic("bf16x6", respect_env=False), deferred_weight_grads(on_param=reported.append) as q:
+            loss().backward()
+        return [p.grad.clone() for m in lin for p in m.parameters()], reported, q.early_flushes
+
+    ref, rep0, n0 = grads(1 << 40)
+    got, rep1, n1 = grads(1 << 20)          # 1 MiB: every second queued layer trips the budget
+    assert n0 == 0 and n1 >= 1
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-6
+    params = [p for m in lin for p in m.parameters()]
+    for rep in (rep0, rep1):
+        assert sorted(id(p) for p in rep) == sorted(id(p) for p in params)     # each exactly once

@@ -44,6 +44,8 @@ af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", ATTN), \
 gf, gw = counter_rows(f"{O}/pmc_gfetch/g_counter_collection.csv", GEMM), counter_rows(f"{O}/pmc_gwrite/g_counter_collection.csv", GEMM)
 (afm, _), (awm, _), (gfm, ng), (gwm, _) = mean(af), mean(aw), mean(gf), mean(gw)
 traffic = {
+    "source": f"profiles/{tag}_attn_coop_B256_L256_pmc_{{fetch,write}}.csv, profiles/{tag}_gemm_act0_bench_step_pmc_{{fetch,write}}.csv "
+              f"(rocprofv3 --pmc passes of tools/profile_round.sh, collected by tools/profile_collect.py {tag})",
     f"attn_relkey_B{B}_L{L}_hbm_bytes_per_launch": (2 * afm + awm) * 1024,
     f"gemm_act0_B{B}_L{L}_hbm_bytes_per_launch": (2 * gfm + gwm) * 1024,
     "_detail": {
