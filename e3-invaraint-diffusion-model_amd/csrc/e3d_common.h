@@ -144,7 +144,13 @@ __device__ __forceinline__ void e3d_absmax_commit(unsigned m, float* target, int
         const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
         m = m > t ? m : t;
     }
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(target), m);
+    // thousands of waves raise ONE address: same-address atomics serialise in L2 (~3 us on a 9-us small-M launch), so a
+    // wave first reads the current value (device-scope load, served by L2) and only joins the queue when it would raise it
+    // -- the target only ever grows, so a stale read can cost an unnecessary atomic, never a missed maximum
+    if (lane == 0) {
+        unsigned* t = reinterpret_cast<unsigned*>(target);
+        if (m > __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(t, m);
+    }
 }
 // May all-padding key tiles be skipped?  Scores are s = (q.k + q.e) / 8 with |q.k| <= 64 qa ka and |q.e| <= 64 qa ea
 // (qa, ka, ea: largest |element| of Q, K and the distance table), so any two scores of a row differ by at most
