@@ -6,7 +6,12 @@ contract (SURVEY.md section 8(b) "Checkpoint format").
 
 Third-party algorithm: ``transformers`` pinned 4.38.2 (reference environment.yml:229), not
 vendored in /root/reference.  Reference call sites: structure_model/model.py:16-20,40,171,177;
-sequence_model/model.py:10-14,39,178.  The ``relative_key`` branch is "parity unpinned".
+sequence_model/model.py:10-14,39,178.  The ``relative_key`` branch is "parity unpinned" against 4.38.2 itself (not
+installed, not vendored).  Independent evidence since round 3: the installed transformers 5.x still ships one
+implementation of HuggingFace's relative_key attention (``Wav2Vec2BertSelfAttention``: distance r - l, clamped);
+``self_attention`` below reproduces its output to 1e-12 in fp64 when handed the mirrored distance table
+(tests/test_oracle_golden.py::test_relative_key_attention_against_an_independent_published_implementation) -- i.e.
+everything of SURVEY App. A steps 1-4 except the sign convention of the distance (l - r in 4.38.2 BertSelfAttention).
 """
 import math
 

@@ -115,6 +115,52 @@ def _blosum():
     return torch.load(os.path.join(GOLDEN, "blosum_substitute.pt"), weights_only=True)
 
 
+def test_relative_key_attention_against_an_independent_published_implementation():
+    """A5 stays "parity unpinned" against the reference's own dependency (transformers 4.38.2 is not installed and not
+    vendored), but the installed transformers 5.x still ships ONE implementation of HuggingFace's ``relative_key``
+    self-attention: ``Wav2Vec2BertSelfAttention`` -- the same einsum("bhld,lrd->bhlr") over a table looked up by pairwise
+    distance, scaled by 1/sqrt(d) with the content scores, additive mask, softmax, PV.  It differs from 4.38.2
+    ``BertSelfAttention`` in two documented ways only: the distance is r - l instead of l - r (so its
+    table is the mirror image: E_w2v[i] = E_bert[2(P-1) - i]) and distances are clamped to [-left, right] (never active
+    for L <= P with left = right = P - 1).  With the mirrored table the oracle's whole attention core -- Q/K/V
+    projections, head split, rel-key term, scaling of BOTH terms, mask, softmax, context merge -- must reproduce that
+    module's output: an independent check of everything in App. A steps 1-4 except the sign convention of the distance,
+    which rests on the published 4.38.2 source alone."""
+    pytest.importorskip("transformers")
+    try:
+        from transformers import Wav2Vec2BertConfig
+        from transformers.models.wav2vec2_bert.modeling_wav2vec2_bert import Wav2Vec2BertSelfAttention
+    except Exception as e:   # noqa: BLE001
+        pytest.skip(f"transformers without Wav2Vec2BertSelfAttention: {e}")
+    torch.manual_seed(0)
+    nh, P, L, B = 3, 24, 19, 2
+    H = nh * 64
+    cfg = Wav2Vec2BertConfig(hidden_size=H, num_attention_heads=nh, position_embeddings_type="relative_key",
+                             left_max_position_embeddings=P - 1, right_max_position_embeddings=P - 1, attention_dropout=0.0)
+    att = Wav2Vec2BertSelfAttention(cfg).eval().double()
+    assert att.distance_embedding.weight.shape == (2 * P - 1, 64)
+    x = torch.randn(B, L, H, dtype=torch.double)
+    mask = (torch.arange(L)[None] < torch.tensor([[L], [11]])).double()
+    bias = ostr.extend_mask(mask)
+    with torch.no_grad():
+        want = att(x, attention_mask=bias)[0]
+    sd = {"a.query.weight": att.linear_q.weight.detach(), "a.query.bias": att.linear_q.bias.detach(),
+          "a.key.weight": att.linear_k.weight.detach(), "a.key.bias": att.linear_k.bias.detach(),
+          "a.value.weight": att.linear_v.weight.detach(), "a.value.bias": att.linear_v.bias.detach(),
+          "a.distance_embedding.weight": att.distance_embedding.weight.detach().flip(0)}
+    ctx = bert.self_attention(sd, "a", x, bias, nh, P)
+    got = torch.nn.functional.linear(ctx, att.linear_out.weight.detach(), att.linear_out.bias.detach())
+    assert rel_err(got, want) < 1e-12
+    # the mirror matters (the check is sensitive to the table's orientation) ...
+    sd_same = dict(sd, **{"a.distance_embedding.weight": att.distance_embedding.weight.detach()})
+    wrong = torch.nn.functional.linear(bert.self_attention(sd_same, "a", x, bias, nh, P), att.linear_out.weight.detach(),
+                                       att.linear_out.bias.detach())
+    assert rel_err(wrong, want) > 1e-3
+    # ... and so does scaling the rel-key term with the content term
+    sd0 = dict(sd, **{"a.distance_embedding.weight": torch.zeros(2 * P - 1, 64, dtype=torch.double)})
+    assert rel_err(bert.self_attention(sd0, "a", x, bias, nh, P), ctx) > 1e-3
+
+
 def test_discrete_schedule_and_transitions_bit_exact():
     fx = load("sequence_utils.pt")
     sched = oseq.NoiseScheduleDiscrete(50)
