@@ -340,7 +340,7 @@ extern "C" int64_t e3d_relkey_attn_bwd_workspace_floats(int B, int nh, int Lq, i
     const int64_t part = relkey ? (int64_t)B * nh * q_tiles * (k_tiles + 1) * 32 * D : 0;
     // [P | dS] of the two-launch kernels; the fused kernel parks the distance-table planes in the same region
     const int64_t head = relkey ? (e3d_attn_bwd_coop_scratch_bytes(Lk) + 3) / 4 : 0;
-    return (2 * pm > head ? 2 * pm : head) + part;
+    return (2 * pm > head ? 2 * pm : head) + part + (relkey ? e3d_attn_bwd_coop_de_floats(Lq, Lk) : 0);
 }
 
 extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
@@ -373,9 +373,9 @@ extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs
         // fused recomputing kernel (attn_bwd_coop.hip): one launch, P / dS never reach HBM
         E3D_REQUIRE(((uintptr_t)workspace % 16) == 0, "attn_bwd: workspace must be 16-byte aligned");
         const int rc = e3d_attn_bwd_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, dout,
-                                                dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, workspace, part, B, nh, Lq,
-                                                Lk, drop, drop_p > 0.f, s);
-        if (rc) return rc;
+                                                dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, d_dist_emb, workspace, part,
+                                                B, nh, Lq, Lk, drop, drop_p > 0.f, s);
+        return rc;     // (incl. the dE reduction: streaming, deterministic)
     } else if (terms == 3) {   // bf16x3 arithmetic (attn_bwd_split.hip); 0 and 6 keep the fp32 MFMA kernels below
         const int rc = e3d_attn_bwd_split_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse,
                                                  dout, dq, dq_bs, dq_rs, dk, dk_bs, dk_rs, dv, dv_bs, dv_rs, Pm, dSm, part, B,

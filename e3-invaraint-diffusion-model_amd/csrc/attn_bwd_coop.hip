@@ -508,6 +508,48 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     }
 }
 
+constexpr int DE_CHUNKS = 12;   // (b, head) chunks of the dE reduction's first stage
+
+// ---- dE = sum of the per-unit partial blocks, streaming and deterministic (the two-launch path's reduce gathers one
+// 256-byte row per unit and E row at a stride of 40 KB -- 36 us for 63 MB at B=32, L=128 -- and ends in float atomics).
+// Stage 1: block (slab = (qt, j), chunk c) sums slab (qt, j) -- 32 x 64 floats, contiguous 8 KB per unit -- over the
+// (b, head) units of chunk c, in unit order: every load is a coalesced 16-byte piece of an 8-KB run.
+__global__ __launch_bounds__(256) void de_chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ chunk_sums,
+                                                           int slabs, int n_bh, int bh_per_chunk) {
+    const int slab = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int b0 = c * bh_per_chunk, b1 = min(n_bh, b0 + bh_per_chunk);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    const float* p = part + ((int64_t)b0 * slabs + slab) * 2048 + 4 * tid;
+    for (int bh = b0; bh < b1; ++bh, p += (int64_t)slabs * 2048) {
+        a0 += *reinterpret_cast<const f32x4*>(p);
+        a1 += *reinterpret_cast<const f32x4*>(p + 1024);
+    }
+    float* o = chunk_sums + ((int64_t)c * slabs + slab) * 2048 + 4 * tid;
+    *reinterpret_cast<f32x4*>(o) = a0;
+    *reinterpret_cast<f32x4*>(o + 1024) = a1;
+}
+// Stage 2: dE[e][d] = sum over chunks and over the (qt, j) slabs whose window holds row e (slab (qt, j) covers rows
+// P + 32 (qt - j) .. + 31), in a fixed order; rows no slab covers (|distance| >= L) get 0.  No memset, no atomics.
+__global__ __launch_bounds__(64) void de_final_sum_kernel(const float* __restrict__ chunk_sums, float* __restrict__ dE, int P,
+                                                          int q_tiles, int k_tiles, int n_chunks) {
+    const int e = blockIdx.x, d = threadIdx.x, slabs = q_tiles * (k_tiles + 1);
+    float acc = 0.f;
+    for (int qt = 0; qt < q_tiles; ++qt) {
+        const int t = 32 * qt + P - e + 31;          // as dist_emb_reduce_kernel: block j = t >> 5, row = e - (32 (qt - j) + P)
+        const int j = t >> 5;
+        if (t < 0 || j > k_tiles) continue;
+        const int row = e - (32 * (qt - j) + P);
+        const float* p = chunk_sums + ((int64_t)(qt * (k_tiles + 1) + j) * 32 + row) * D + d;
+        float v[DE_CHUNKS];       // all chunk loads of a slab in flight together, summed in chunk order
+#pragma unroll
+        for (int c = 0; c < DE_CHUNKS; ++c) v[c] = p[(int64_t)min(c, n_chunks - 1) * slabs * 2048];
+#pragma unroll
+        for (int c = 0; c < DE_CHUNKS; ++c)
+            if (c < n_chunks) acc += v[c];
+    }
+    dE[(int64_t)e * D + d] = acc;
+}
+
 }  // namespace
 
 // bytes of scratch the fused kernel needs for the two plane orders of the distance table (inside the caller's workspace)
@@ -523,14 +565,20 @@ bool e3d_attn_bwd_coop_supported(int Lq, int Lk, bool dropping) {
     return on && Lq <= 32 * MAX_TILES && Lk <= 32 * MAX_TILES;
 }
 
+// chunk partial sums of the dE reduction: floats appended to the unit blocks in the caller's workspace
+int64_t e3d_attn_bwd_coop_de_floats(int Lq, int Lk) {
+    return (int64_t)DE_CHUNKS * ((Lq + 31) / 32) * ((Lk + 31) / 32 + 1) * 2048;
+}
+
 // The fused backward, bf16x3 (arguments validated by e3d_relkey_attn_bwd_ex; ``e_scratch``: 16-byte aligned,
-// e3d_attn_bwd_coop_scratch_bytes(Lk) bytes, only read / written when dist_emb is given; the caller runs the dE reduce).
+// e3d_attn_bwd_coop_scratch_bytes(Lk) bytes, only read / written when dist_emb is given; ``part``: the unit blocks
+// followed by e3d_attn_bwd_coop_de_floats(Lq, Lk) floats; writes every row of d_dist_emb).
 int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                              const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                              const float* key_mask, const float* out, const float* lse, const float* dout, float* dq,
                              int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs, float* dv,
-                             int64_t dv_bs, int64_t dv_rs, void* e_scratch, float* part, int B, int nh, int Lq, int Lk,
-                             E3dDrop drop, bool dropping, hipStream_t s) {
+                             int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, void* e_scratch, float* part, int B, int nh,
+                             int Lq, int Lk, E3dDrop drop, bool dropping, hipStream_t s) {
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
     bf16x8* e_row = reinterpret_cast<bf16x8*>(e_scratch);
     bf16x8* e_tr = e_row ? e_row + n_items : nullptr;
@@ -552,5 +600,13 @@ int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const f
         else E3D_BWD_COOP(false, false);
     }
 #undef E3D_BWD_COOP
+    if (dist_emb) {
+        const int q_tiles = (Lq + 31) / 32, k_tiles = (Lk + 31) / 32, slabs = q_tiles * (k_tiles + 1), n_bh = B * nh;
+        const int per = (n_bh + DE_CHUNKS - 1) / DE_CHUNKS, n_chunks = (n_bh + per - 1) / per;
+        float* chunk_sums = part + (int64_t)n_bh * slabs * 2048;
+        hipLaunchKernelGGL(de_chunk_sum_kernel, dim3(slabs, n_chunks), dim3(256), 0, s, part, chunk_sums, slabs, n_bh, per);
+        hipLaunchKernelGGL(de_final_sum_kernel, dim3(2 * P - 1), dim3(64), 0, s, chunk_sums, d_dist_emb, P, q_tiles, k_tiles,
+                           n_chunks);
+    }
     return e3d_launch_status("e3d_relkey_attn_bwd (fused, bf16x3)");
 }

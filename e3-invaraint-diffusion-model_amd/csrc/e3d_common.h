@@ -207,13 +207,14 @@ int e3d_attn_bwd_split_launch(const float* q, int64_t q_bs, int64_t q_rs, const 
 
 // attn_bwd_coop.hip: the fused, recomputing backward (bf16x3, Lq, Lk <= 128); internal
 int64_t e3d_attn_bwd_coop_scratch_bytes(int Lk);
+int64_t e3d_attn_bwd_coop_de_floats(int Lq, int Lk);
 bool e3d_attn_bwd_coop_supported(int Lq, int Lk, bool dropping);
 int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                              const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                              const float* key_mask, const float* out, const float* lse, const float* dout, float* dq,
                              int64_t dq_bs, int64_t dq_rs, float* dk, int64_t dk_bs, int64_t dk_rs, float* dv,
-                             int64_t dv_bs, int64_t dv_rs, void* e_scratch, float* part, int B, int nh, int Lq, int Lk,
-                             E3dDrop drop, bool dropping, hipStream_t s);
+                             int64_t dv_bs, int64_t dv_rs, float* d_dist_emb, void* e_scratch, float* part, int B, int nh,
+                             int Lq, int Lk, E3dDrop drop, bool dropping, hipStream_t s);
 
 // XCD-aware remap (cdna_hip_programming.md T1, bijective form): consecutive logical ids
 // land on one XCD so that workgroups sharing operands share an L2.
