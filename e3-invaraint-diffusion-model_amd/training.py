@@ -28,6 +28,30 @@ def adamw(params, lr, weight_decay):
 from . import autograd, ops, sharding
 
 
+def clip_and_step(params, optim, max_norm):
+    """``clip_grad_norm_(params, max_norm)`` + ``optim.step()`` (what Lightning's ``gradient_clip_val`` does around the
+    reference's AdamW, structure_model/train_model.py:99-110) with the clip FOLDED INTO the fused optimizer kernel: torch's
+    fused AdamW divides every gradient by a device scalar ``grad_scale`` on load (the hook GradScaler uses), so handing it
+    1 / clip_coef applies the clip inside the update pass instead of a separate read-modify-write pass over all gradients
+    (9 multi-tensor launches, 0.27 ms of the 146 M-parameter structure step).  Same clip coefficient as torch
+    (min(1, max_norm / (total_norm + 1e-6))); g / (1 / c) instead of g * c differs by an ulp.  Falls back to the two calls
+    when the optimizer is not a fused Adam(W).  Returns the total gradient norm (device tensor), like clip_grad_norm_."""
+    grads = [p.grad for p in params if p.grad is not None]
+    fused = bool(optim.defaults.get("fused")) and isinstance(optim, (torch.optim.AdamW, torch.optim.Adam))
+    if not max_norm or not grads or not fused or not hasattr(torch.nn.utils, "get_total_norm"):
+        norm = torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm else None
+        optim.step()
+        return norm
+    norm = torch.nn.utils.get_total_norm(grads, 2.0, error_if_nonfinite=False, foreach=True)
+    coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    optim.grad_scale = (1.0 / coef).to(torch.float32)
+    try:
+        optim.step()
+    finally:
+        optim.grad_scale = None
+    return norm
+
+
 def move_batch(batch, device):
     return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
@@ -98,9 +122,7 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             else:
                 loss.backward()
             averager.average()                       # RCCL all-reduce (no-op for one process)
-            if gradient_clip:
-                torch.nn.utils.clip_grad_norm_(params, gradient_clip)   # global norm of the averaged grads
-            optim.step()
+            clip_and_step(params, optim, gradient_clip)   # global-norm clip of the averaged grads, inside the AdamW kernel
             ops.invalidate_weight_caches()           # belt and braces beside the global optimizer hook (ops.py)
             if sched is not None and sched.get("interval") == "step":
                 sched["scheduler"].step()

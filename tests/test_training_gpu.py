@@ -99,3 +99,32 @@ def test_bench_two_rank_rehearsal_reports_the_data_parallel_training_leg():
     ddp = out["train_ddp"]
     assert ddp["ranks"] == 2 and ddp["global_batch"] == 8 and ddp["backend"] == "gloo" and ddp["ms_per_step"] > 0
     assert ddp["model"] == "sequence" and ddp["buckets"] >= 1 and "train" not in out
+
+
+def test_clip_folded_into_the_fused_adamw_matches_clip_then_step(pkg, hip):
+    """training.clip_and_step hands torch's fused AdamW 1 / clip_coef as ``grad_scale``: the parameters after the step equal
+    those of clip_grad_norm_ + step (an ulp from g / (1/c) vs g * c), with the clip active and inactive."""
+    from e3diff_amd.training import adamw, clip_and_step
+    for scale in (50.0, 1e-3):           # gradient norm far above / below max_norm = 1
+        torch.manual_seed(0)
+        base = [torch.randn(257, 33, device="cuda:0"), torch.randn(1000, device="cuda:0")]
+        grads = [torch.randn_like(p) * scale for p in base]
+        outs = []
+        for folded in (False, True):
+            ps = [torch.nn.Parameter(p.clone()) for p in base]
+            for p, g_ in zip(ps, grads):
+                p.grad = g_.clone()
+            opt = adamw(ps, lr=1e-2, weight_decay=0.1)
+            assert opt.defaults.get("fused")
+            for _ in range(2):
+                if folded:
+                    n = clip_and_step(ps, opt, 1.0)
+                else:
+                    n = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+                    opt.step()
+            outs.append(([p.detach().clone() for p in ps], float(n)))
+        # (the second step sees the gradients the first one left behind: torch's kernel writes the unscaled gradient back,
+        #  clip_grad_norm_ scales in place -- the same values up to an ulp)
+        assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[0][1]
+        for a, b in zip(outs[0][0], outs[1][0]):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)

@@ -78,8 +78,7 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
             loss.backward()
         if averager is not None:
             averager.average()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        optim.step()
+        pkg.training.clip_and_step(params, optim, 1.0)      # as training.fit does
         return loss
 
     with pkg.ops.arithmetic(pkg.training.TRAIN_ARITHMETIC):   # bf16x3 unless E3D_GEMM_MODE says otherwise
