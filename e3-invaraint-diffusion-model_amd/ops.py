@@ -380,7 +380,17 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
                     scratch, ready, e_abs = ent[1], 1, ent[2]
                 else:
                     scratch = torch.empty((hip.lib().e3d_attn_scratch_bytes(Lk),), device=q.device, dtype=torch.uint8)
-                    e_abs = absmax(dist_emb.detach()) if q_abs is not None else None
+                    # training (weights change every step): a pool slot of the table, raised by this call -- never lowered,
+                    # so a value from an earlier step is still a bound; inference keeps a scalar of its own with the planes
+                    # (a pool slot would be zeroed by the next chain's reset while the cached planes live on)
+                    e_abs = None
+                    if q_abs is not None and not infer:
+                        try:
+                            e_abs = absmax(dist_emb.detach(), absmax_slot(dist_emb, "e", q.device))
+                        except AttributeError:
+                            e_abs = absmax(dist_emb.detach())
+                    elif q_abs is not None:
+                        e_abs = absmax(dist_emb.detach())
                     if infer and not torch.cuda.is_current_stream_capturing():
                         try:
                             if e_abs is None:
