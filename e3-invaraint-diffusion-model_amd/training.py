@@ -28,17 +28,20 @@ def adamw(params, lr, weight_decay):
 from . import autograd, ops, sharding
 
 
-def clip_and_step(params, optim, max_norm):
-    """``clip_grad_norm_(params, max_norm)`` + ``optim.step()`` (what Lightning's ``gradient_clip_val`` does around the
-    reference's AdamW, structure_model/train_model.py:99-110) with the clip FOLDED INTO the fused optimizer kernel: torch's
-    fused AdamW divides every gradient by a device scalar ``grad_scale`` on load (the hook GradScaler uses), so handing it
-    1 / clip_coef applies the clip inside the update pass instead of a separate read-modify-write pass over all gradients
-    (9 multi-tensor launches, 0.27 ms of the 146 M-parameter structure step).  Same clip coefficient as torch
-    (min(1, max_norm / (total_norm + 1e-6))); g / (1 / c) instead of g * c differs by an ulp.  Falls back to the two calls
-    when the optimizer is not a fused Adam(W).  Returns the total gradient norm (device tensor), like clip_grad_norm_."""
+def clip_and_step(params, optim, max_norm, fold=None):
+    """``clip_grad_norm_(params, max_norm)`` + ``optim.step()`` -- what Lightning's ``gradient_clip_val`` does around the
+    reference's AdamW (structure_model/train_model.py:99-110).  Returns the total gradient norm (device tensor).
+    ``fold`` (E3D_FOLD_CLIP=1): hand torch's fused AdamW 1 / clip_coef as its ``grad_scale`` (the GradScaler hook) so that
+    the clip happens inside the update kernel instead of a separate multi-tensor pass.  Measured on MI355X (146 M
+    parameters, rocprofv3): the multiply pass it removes costs 0.27 ms, but the fused kernel with a grad_scale also writes
+    every unscaled gradient back and goes from 59 to 93 us per launch x 17 = +0.59 ms -- a net LOSS of 0.3 ms, so the
+    two-call form stays the default; the folded form is kept for the comparison (tests/test_training_gpu.py pins that both
+    give the same parameters)."""
+    if fold is None:
+        fold = os.environ.get("E3D_FOLD_CLIP", "0") == "1"
     grads = [p.grad for p in params if p.grad is not None]
     fused = bool(optim.defaults.get("fused")) and isinstance(optim, (torch.optim.AdamW, torch.optim.Adam))
-    if not max_norm or not grads or not fused or not hasattr(torch.nn.utils, "get_total_norm"):
+    if not fold or not max_norm or not grads or not fused or not hasattr(torch.nn.utils, "get_total_norm"):
         norm = torch.nn.utils.clip_grad_norm_(params, max_norm) if max_norm else None
         optim.step()
         return norm
@@ -122,7 +125,7 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             else:
                 loss.backward()
             averager.average()                       # RCCL all-reduce (no-op for one process)
-            clip_and_step(params, optim, gradient_clip)   # global-norm clip of the averaged grads, inside the AdamW kernel
+            clip_and_step(params, optim, gradient_clip)   # global-norm clip of the averaged grads, then AdamW
             ops.invalidate_weight_caches()           # belt and braces beside the global optimizer hook (ops.py)
             if sched is not None and sched.get("interval") == "step":
                 sched["scheduler"].step()

@@ -102,8 +102,9 @@ def test_bench_two_rank_rehearsal_reports_the_data_parallel_training_leg():
 
 
 def test_clip_folded_into_the_fused_adamw_matches_clip_then_step(pkg, hip):
-    """training.clip_and_step hands torch's fused AdamW 1 / clip_coef as ``grad_scale``: the parameters after the step equal
-    those of clip_grad_norm_ + step (an ulp from g / (1/c) vs g * c), with the clip active and inactive."""
+    """training.clip_and_step(fold=True) hands torch's fused AdamW 1 / clip_coef as ``grad_scale``: the parameters after the
+    step equal those of clip_grad_norm_ + step (an ulp from g / (1/c) vs g * c), with the clip active and inactive.  (The
+    folded form measured slower on MI355X and is not the default: see the function's docstring.)"""
     from e3diff_amd.training import adamw, clip_and_step
     for scale in (50.0, 1e-3):           # gradient norm far above / below max_norm = 1
         torch.manual_seed(0)
@@ -118,7 +119,7 @@ def test_clip_folded_into_the_fused_adamw_matches_clip_then_step(pkg, hip):
             assert opt.defaults.get("fused")
             for _ in range(2):
                 if folded:
-                    n = clip_and_step(ps, opt, 1.0)
+                    n = clip_and_step(ps, opt, 1.0, fold=True)
                 else:
                     n = torch.nn.utils.clip_grad_norm_(ps, 1.0)
                     opt.step()
