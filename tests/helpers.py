@@ -122,3 +122,29 @@ def rescaled_state_dict(sd, weight_scale=4.0, gamma_range=(0.5, 2.0), seed=0):
         else:
             out[k] = v.clone()
     return out
+
+
+def heavy_tailed_state_dict(sd, seed=0):
+    """A third weight regime for the arithmetic-margin tests, shaped like trained transformer weights rather than like an
+    initialiser: every Linear weight row gets its own log-normal scale (sigma 0.5: rows differ by up to ~5x), 0.5 % of the
+    entries are outliers (x8), biases x3, LayerNorm gammas log-uniform in [0.3, 3] with 1 % of the channels at x6 (the
+    "massive activation" channels of trained LayerNorms), distance tables x0.5."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        if "LayerNorm.weight" in k or "layer_norm.weight" in k:
+            gam = torch.exp(math.log(0.3) + (math.log(3.0) - math.log(0.3)) * torch.rand(v.shape, generator=g))
+            gam = torch.where(torch.rand(v.shape, generator=g) < 0.01, gam * 6.0, gam)
+            out[k] = gam
+        elif k.endswith("distance_embedding.weight"):
+            out[k] = v * 0.5
+        elif v.dim() == 2 and k.endswith(".weight"):
+            rows = torch.exp(0.5 * torch.randn(v.shape[0], 1, generator=g))
+            w = v * rows
+            w = torch.where(torch.rand(v.shape, generator=g) < 0.005, w * 8.0, w)
+            out[k] = w.contiguous()
+        elif k.endswith(".bias") and v.dim() == 1:
+            out[k] = v * 3.0
+        else:
+            out[k] = v.clone()
+    return out
