@@ -504,12 +504,15 @@ def main():
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_train
-        ddp = bench_train.run("sequence", batch=args.train_ddp_batch, seq_len=args.train_ddp_seq_len, steps=5, warmup=2,
-                              device=str(device), ddp=True, layers=args.train_ddp_layers, seed=rank)
+        try:
+            ddp = bench_train.run("sequence", batch=args.train_ddp_batch, seq_len=args.train_ddp_seq_len, steps=5, warmup=2,
+                                  device=str(device), ddp=True, layers=args.train_ddp_layers, seed=rank)
+            ddp["note"] = ("sequence model (reference sequence_model/train_model.py:93-104 under DDP), forward + loss + "
+                           "backward + gradient all-reduce / world + clip + AdamW; ms_per_step = max over ranks")
+        except Exception as e:   # noqa: BLE001 -- an extra key must never cost the headline line (the same code path on
+            ddp = {"error": f"{type(e).__name__}: {e}"}   # every rank: a Python error is raised by all of them alike)
         if rank == 0:
-            out["train_ddp"] = dict(ddp, note="sequence model (reference sequence_model/train_model.py:93-104 under DDP), "
-                                              "forward + loss + backward + gradient all-reduce / world + clip + AdamW; "
-                                              "ms_per_step = max over ranks")
+            out["train_ddp"] = ddp
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -98,7 +98,7 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
     if ddp and dist.is_initialized():
         from e3diff_amd import sharding
         dt = sharding.max_over_ranks(dt)
-        w = torch.cat([p.detach().reshape(-1)[:64] for p in params]).double().sum()
+        w = torch.cat([p.detach().reshape(-1)[:64] for p in params]).double().sum().reshape(1)
         ws = [torch.zeros_like(w) for _ in range(dist.get_world_size())]
         if dist.get_backend() != "nccl":
             w = w.cpu()
