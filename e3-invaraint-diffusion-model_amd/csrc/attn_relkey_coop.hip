@@ -162,12 +162,14 @@ __device__ long long e3d_attn_stamps[16][8];
 #define KSTAMP(i) do {} while (0)
 #endif
 
-template <int W, bool RELKEY, typename E>
+// DROP (training): dropout multipliers on the probabilities, regenerated from (seed, element index) exactly as the
+// per-wave kernel and the backward do (e3d_common.h); the row sum stays un-dropped (softmax first, then dropout).
+template <int W, bool RELKEY, typename E, bool DROP = false>
 __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const typename AV<E>::x8* __restrict__ e_frag,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq, int Lk,
-    int groups_per_bh, int skip_padded_tiles, E3dBounds bnd, float rescale_tau) {
+    int groups_per_bh, int skip_padded_tiles, E3dBounds bnd, float rescale_tau, E3dDrop drop) {
     typedef typename AV<E>::x8 bf16x8;   // (names kept from the bf16 form: 8 / 4 split terms of type E)
     typedef typename AV<E>::x4 bf16x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -404,6 +406,15 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             psum += s[r];
         }
         l_run += psum;
+        if (DROP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float m[4];
+                e3d_drop_mult4(drop, e3d_attn_drop_idx4(bh, Lq, Lk, min(q0 + qi, Lq - 1), kt * 32 + 8 * g + 4 * half), m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] *= m[j];
+            }
+        }
         ASTAMP(4);
 
         // O^T += V^T P^T: two 16-key steps; P^T registers 8 st .. 8 st + 7 are the B operand (keys
@@ -488,13 +499,24 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
 template <int W, bool RELKEY, typename E>
 int launch_w(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs, const float* v,
              int64_t v_bs, int64_t v_rs, const void* e_frag, int P, const float* key_mask,
-             float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip, E3dBounds bnd, hipStream_t s) {
+             float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip, E3dBounds bnd, E3dDrop drop,
+             bool dropping, hipStream_t s) {
     const size_t lds = 2 * KV_BUF_B + (size_t)W * RING_F * sizeof(float);
+    const int groups = q_tiles / W;
+    if constexpr (std::is_same<E, __bf16>::value) {   // dropout exists in the training arithmetic (bf16x3) only
+        if (dropping) {
+            static std::atomic<uint64_t> lds_ok_d{0};
+            e3d_allow_lds(lds_ok_d, attn_coop_kernel<W, RELKEY, E, true>, lds);
+            hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY, E, true>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs,
+                               k, k_bs, k_rs, v, v_bs, v_rs, reinterpret_cast<const typename AV<E>::x8*>(e_frag), P, key_mask,
+                               out, lse, nh, Lq, Lk, groups, skip, bnd, g_rescale_tau, drop);
+            return e3d_launch_status("e3d_relkey_attn_fwd_split (cooperative, dropout)");
+        }
+    }
     static std::atomic<uint64_t> lds_ok{0};
     e3d_allow_lds(lds_ok, attn_coop_kernel<W, RELKEY, E>, lds);
-    const int groups = q_tiles / W;
     hipLaunchKernelGGL((attn_coop_kernel<W, RELKEY, E>), dim3(B * nh * groups), dim3(W * 64), lds, s, q, q_bs, q_rs, k, k_bs,
-                       k_rs, v, v_bs, v_rs, reinterpret_cast<const typename AV<E>::x8*>(e_frag), P, key_mask, out, lse, nh, Lq, Lk, groups, skip, bnd, g_rescale_tau);
+                       k_rs, v, v_bs, v_rs, reinterpret_cast<const typename AV<E>::x8*>(e_frag), P, key_mask, out, lse, nh, Lq, Lk, groups, skip, bnd, g_rescale_tau, drop);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (cooperative)");
 }
 
@@ -502,11 +524,11 @@ template <bool RELKEY, typename E>
 int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                const float* v, int64_t v_bs, int64_t v_rs, const void* e_frag, int P,
                const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int q_tiles, int skip,
-               E3dBounds bnd, hipStream_t s) {
+               E3dBounds bnd, E3dDrop drop, bool dropping, hipStream_t s) {
 #define E3D_COOP_CASE(w)                                                                                          \
     case w:                                                                                                       \
         return launch_w<w, RELKEY, E>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_frag, P, key_mask, out, lse, B, nh, \
-                                   Lq, Lk, q_tiles, skip, bnd, s)
+                                   Lq, Lk, q_tiles, skip, bnd, drop, dropping, s)
     switch (W) {
         E3D_COOP_CASE(8);
         E3D_COOP_CASE(4);
@@ -523,7 +545,7 @@ template <typename E>
 static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         E3dBounds bnd, void* e_scratch, int e_ready, hipStream_t s) {
+                         E3dBounds bnd, void* e_scratch, int e_ready, E3dDrop drop, bool dropping, hipStream_t s) {
     const int q_tiles = (Lq + 31) / 32;
     static int w_max = 0;   // E3D_ATTN_W caps the waves per workgroup (experiments)
     if (!w_max) {
@@ -534,7 +556,7 @@ static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float
     while (W > w_max && W > 1) W >>= 1;
     if (!dist_emb)
         return launch_any<false, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, q_tiles, skip, bnd, s);
+                                    Lq, Lk, q_tiles, skip, bnd, drop, dropping, s);
     // distance table -> fragment-order hi / lo planes in the caller's scratch (e3d_attn_scratch_bytes(Lk) bytes)
     if (!e_scratch) {
         e3d_set_error("attn_coop: rel-key attention needs the caller's scratch for the distance-table planes");
@@ -545,7 +567,7 @@ static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float
         hipLaunchKernelGGL(e_fragments_kernel<E>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
                            reinterpret_cast<typename AV<E>::x8*>(e_scratch), P, J0, n_items);
     return launch_any<true, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_scratch, P, key_mask, out, lse, B, nh, Lq,
-                               Lk, q_tiles, skip, bnd, s);
+                               Lk, q_tiles, skip, bnd, drop, dropping, s);
 }
 
 // bf16x3 / f16x3 attention, cooperative kernel.  Same contract as e3d_relkey_attn_fwd_split with terms = 3 / 19
@@ -553,12 +575,12 @@ static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float
 int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
                          const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
                          const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         E3dBounds bnd, void* e_scratch, int e_ready, int f16, hipStream_t s) {
+                         E3dBounds bnd, void* e_scratch, int e_ready, int f16, E3dDrop drop, bool dropping, hipStream_t s) {
     if (f16)
         return coop_launch_t<_Float16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq,
-                                       Lk, skip, bnd, e_scratch, e_ready, s);
+                                       Lk, skip, bnd, e_scratch, e_ready, drop, dropping, s);
     return coop_launch_t<__bf16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk,
-                                 skip, bnd, e_scratch, e_ready, s);
+                                 skip, bnd, e_scratch, e_ready, drop, dropping, s);
 }
 
 // Diagnostic (tests): threshold of the deferred rescale in log2 units; 0 = raise the maximum on every new one (classic

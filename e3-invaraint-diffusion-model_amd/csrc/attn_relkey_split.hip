@@ -392,24 +392,26 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
         if (rc) return rc;
         e_scratch_ready = 1;
     }
-    if (drop_p > 0.f) {   // training with attention-probability dropout: per-wave kernel
-        const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
-        if (terms == 3)
-            return launch<2, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
-        return launch<3, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
-    }
     static int coop = -1;   // E3D_ATTN_COOP=0: per-wave kernel below for every shape (A/B experiments)
     if (coop < 0) {
         const char* e = getenv("E3D_ATTN_COOP");
         coop = e ? atoi(e) : 1;
     }
+    const bool dropping = drop_p > 0.f;
+    const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
     // two-wave groups (q_tiles % 4 != 0) measured slower than the per-wave kernel: too little sharing per barrier
     // the cooperative kernel reads the distance table as fragment-order bf16 planes from a CALLER-provided scratch
-    // (e3d_attn_scratch_bytes); without one the per-wave kernel below serves the call -- the library never allocates
-    if ((terms == 3 || f16) && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1) &&
+    // (e3d_attn_scratch_bytes); without one the per-wave kernel below serves the call -- the library never allocates.
+    // With dropout (training) the cooperative kernel exists in bf16x3.
+    if ((terms == 3 || (f16 && !dropping)) && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && (((Lq + 31) / 32) % 4 == 0 || coop > 1) &&
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
-                                    Lq, Lk, g_skip_padded, bnd, e_scratch, e_scratch_ready, f16, s);
+                                    Lq, Lk, g_skip_padded, bnd, e_scratch, e_scratch_ready, f16, d, dropping, s);
+    if (dropping) {   // training with attention-probability dropout, other shapes / arithmetics: per-wave kernel
+        if (terms == 3)
+            return launch<2, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
+        return launch<3, true>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh, Lq, Lk, bnd, s, d);
+    }
     if (f16)
         return launch<2, false, _Float16>(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
                                           Lq, Lk, bnd, s);

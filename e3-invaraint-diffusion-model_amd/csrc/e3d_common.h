@@ -16,11 +16,6 @@ void e3d_set_error(const char* fmt, ...);
 // device scalars bounding |Q|, |K| and |distance table| elements of an attention call (e3d_mask_skip_is_exact below)
 struct E3dBounds { const float* q; const float* k; const float* e; };
 
-// attn_relkey_coop.hip: workgroup-cooperative bf16x3 attention forward (internal; arguments validated by the caller)
-int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
-                         const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
-                         const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
-                         struct E3dBounds bnd, void* e_scratch, int e_ready, int f16, hipStream_t s);
 
 #define E3D_REQUIRE(cond, ...)       \
     do {                             \
@@ -196,6 +191,13 @@ __device__ __forceinline__ uint64_t e3d_attn_drop_idx4(int bh, int Lq, int Lk, i
 }
 
 int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, hipStream_t s);
+
+// attn_relkey_coop.hip: workgroup-cooperative bf16x3 / f16x3 attention forward (internal; arguments validated by the
+// caller); ``dropping``: dropout on the probabilities (bf16x3 only)
+int e3d_attn_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
+                         const float* v, int64_t v_bs, int64_t v_rs, const float* dist_emb, int P,
+                         const float* key_mask, float* out, float* lse, int B, int nh, int Lq, int Lk, int skip,
+                         E3dBounds bnd, void* e_scratch, int e_ready, int f16, E3dDrop drop, bool dropping, hipStream_t s);
 
 // attn_bwd_split.hip: launches A and B of the attention backward in bf16x3 arithmetic (internal)
 int e3d_attn_bwd_split_launch(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs, int64_t k_rs,
