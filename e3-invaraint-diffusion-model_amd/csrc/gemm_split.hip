@@ -846,8 +846,13 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     }
     if constexpr (!A_KMAJ && !B_KMAJ) {
         if constexpr (NS == 2) {
+            // the persistent kernel from 160 tiles upwards -- and from 96 when the output is at least 6 tiles wide (N >= 1536):
+            // there the 128x128 form needs 1.5+ rounds of 256 CUs (M = 4096, N = 1536: 384 tiles), one 256x256 tile per CU
+            // is faster (structure training step 32.0 -> 31.1 ms); narrow outputs with 96-159 tiles (M = 8192, N = 768)
+            // measured 6 % slower on it (sequence step 25.0 -> 26.6 ms) and stay on the 128x128 form
+            const int64_t n_tiles = (int64_t)(M / BT) * (N / BT);
             if (N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && K >= 2 * BK && lda < (1 << 22) &&
-                (int64_t)(M / BT) * (N / BT) >= p_min())
+                (n_tiles >= p_min() || (n_tiles >= 96 && N >= 6 * BT && !getenv("E3D_GEMM_P_MIN"))))
                 return launch256p<ACT, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
             if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
                 return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
