@@ -808,7 +808,7 @@ int launch256p(const float* A, int64_t lda, const float* W, const float* bias, f
 
 int g_general_form = -1;   // E3D_GEMM_FORM, e3d_gemm_general_select: 0 = by shape
 int g_tile_pref = -1;  // E3D_GEMM_TILE (A/B runs): 0 = 256x128 (8 waves of 64x64) for every shape, 1 = 256x256 classic
-                       // loop, 3 = 256x256 with interleaved staging, 4 = + persistent (default)
+                       // loop, 3 = 256x256 with interleaved staging, 4 = + persistent (default), 5 = persistent for EVERY tile count (lab)
 
 template <int NS, int ACT, int WR, int WC, int NBUF, bool PIPE, typename E>
 int launch256(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
@@ -852,7 +852,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
             // measured 6 % slower on it (sequence step 25.0 -> 26.6 ms) and stay on the 128x128 form
             const int64_t n_tiles = (int64_t)(M / BT) * (N / BT);
             if (N % BT == 0 && M % BT == 0 && ldb == K && g_tile_pref >= 4 && K >= 2 * BK && lda < (1 << 22) &&
-                (n_tiles >= p_min() || (n_tiles >= 96 && N >= 6 * BT && !getenv("E3D_GEMM_P_MIN"))))
+                (g_tile_pref >= 5 || n_tiles >= p_min() || (n_tiles >= 96 && N >= 6 * BT && !getenv("E3D_GEMM_P_MIN"))))
                 return launch256p<ACT, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
             if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
                 return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);

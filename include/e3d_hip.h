@@ -147,7 +147,7 @@ int e3d_gemm_skinny_residual_layernorm_f32_split_ex(const float* A, int64_t lda,
 
 /* Diagnostic switch (A/B timing, tools/bench_kernels.py): which kernel form serves large-M forward launches of
  * e3d_gemm_bias_act_f32_split with terms = 3 -- 4 = persistent 256x256 (default), 3 = 256x256 with interleaved
- * staging, 1 = classic 256x256 loop, 0 = 256x128.  Results are identical in every form (same products, same
+ * staging, 1 = classic 256x256 loop, 0 = 256x128, 5 = persistent whatever the tile count (experiments).  Results are identical in every form (same products, same
  * accumulation order).  pref < 0 only queries.  Returns the previous value. */
 int e3d_gemm_kernel_select(int pref);
 /* The same for the general kernel (every launch the persistent / 256x256 forms do not take: medium and small M, the
