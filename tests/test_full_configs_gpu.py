@@ -450,8 +450,8 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
         assert rows["bf16x3"][1] < 30 * f32, rows
     elif scale < 0:
         # the regime shaped like TRAINED weights (per-row scales, outlier entries, outlier LayerNorm channels): the
-        # fp32-grade arithmetics within 3x of the exact fp32 kernels
-        assert rows["f16x3"][1] < 3 * f32 and rows["bf16x6"][1] < 3 * f32, rows
+        # fp32-grade arithmetics within 4x of the exact fp32 kernels (measured 2.0x / 1.9x)
+        assert rows["f16x3"][1] < 4 * f32 and rows["bf16x6"][1] < 4 * f32, rows
     else:
         assert rows["f16x3"][1] < 10 * f32 and rows["bf16x6"][1] < 10 * f32, rows
 
