@@ -18,6 +18,7 @@ if __package__ in (None, ""):  # executed as a script from inside this directory
 
 import os
 import pickle
+import warnings
 
 import torch
 from torch import nn
@@ -292,12 +293,21 @@ def sample(model, test_angle_ds, all_batches: bool = False):
         print(f"Generating Batch {idx}/{len(ligand_mask)}")
         lengths = lm.sum(dim=1).int()
         x_T = test_angle_ds.sample_noise(torch.zeros((len(lengths), pad, feature_size)))
-        with ops.arithmetic(ARITHMETIC):
-            sampled = p_sample_loop(
-                model=model, ligand_mask=lm.to(DEVICE), ligand_angle_noise=x_T.to(DEVICE),
-                receptor_seq=receptor_seq[idx].to(DEVICE), receptor_mask=receptor_mask[idx].to(DEVICE),
-                receptor_angle=receptor_angle[idx].to(DEVICE), total_timesteps=test_angle_ds.timesteps,
-                betas=test_angle_ds.alpha_beta_terms["betas"], trim_padding=True)   # sliced to l_i right below
+        def chain(arithmetic):
+            with ops.arithmetic(arithmetic):
+                return p_sample_loop(
+                    model=model, ligand_mask=lm.to(DEVICE), ligand_angle_noise=x_T.to(DEVICE),
+                    receptor_seq=receptor_seq[idx].to(DEVICE), receptor_mask=receptor_mask[idx].to(DEVICE),
+                    receptor_angle=receptor_angle[idx].to(DEVICE), total_timesteps=test_angle_ds.timesteps,
+                    betas=test_angle_ds.alpha_beta_terms["betas"], trim_padding=True)   # sliced to l_i right below
+
+        sampled = chain(ARITHMETIC)
+        if ops.GEMM_MODES.get(ARITHMETIC) == 19 and "E3D_GEMM_MODE" not in os.environ and not bool(torch.isfinite(sampled).all()):
+            # f16x3's one remaining range limit: an ACTIVATION beyond 65504 (weights are pre-scaled) turns into inf / NaN.
+            # The chain is then run again in bf16x6 -- same fp32 grade, fp32 exponent range, half the speed -- and says so
+            warnings.warn("structure sampling: non-finite angles in f16x3 arithmetic (an activation left the fp16 range); "
+                          "re-running this batch in bf16x6")
+            sampled = chain("bf16x6")
         retval.extend(sampled[:, i, :l, :].numpy() for i, l in enumerate(lengths))
         if not all_batches:
             break

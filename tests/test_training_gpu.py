@@ -129,3 +129,37 @@ def test_clip_folded_into_the_fused_adamw_matches_clip_then_step(pkg, hip):
         assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[0][1]
         for a, b in zip(outs[0][0], outs[1][0]):
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_structure_sample_entry_point_and_its_f16x3_safety_net(pkg, hip, monkeypatch):
+    """structure_model/sample.py::sample on a small model: one array [T, l_i, 8] per pocket, finite, in [-pi, pi].  Then
+    the one range limit f16x3 has left: a weight pattern that drives an activation past 65504 gives
+    non-finite angles in f16x3 -- ``sample`` notices, says so, and returns the bf16x6 result instead."""
+    import warnings
+    from e3diff_amd.structure_model import sample as S
+    from e3diff_amd.structure_model.dataset import LigandBindingSiteDataset, NoisedAnglesDataset
+    cfg = dict(S.CONFIG, hidden_size=256, num_heads=4, intermediate_size=512, num_hidden_layers=1, max_seq_len=64, batch_size=4,
+               timesteps=6, pocket_ext=1)
+    monkeypatch.setattr(S, "CONFIG", cfg)
+    monkeypatch.setattr(S, "DEVICE", "cuda:0")
+    monkeypatch.setattr(S, "MODEL_PATH", None)
+    monkeypatch.delenv("E3D_GEMM_MODE", raising=False)
+    ds = NoisedAnglesDataset(LigandBindingSiteDataset(None, "test", cfg["max_seq_len"], cfg["pocket_ext"], records=_records(40)),
+                             timesteps=cfg["timesteps"])
+    torch.manual_seed(0)
+    model = S.load_model(ds)
+    with torch.no_grad():       # adaLN_modulation[0] is zero-initialised: give the gated branches weights
+        for se in (model.receptor_emb, model.timestep_emb):
+            torch.nn.init.normal_(se.adaLN_modulation[0].weight, std=0.02)
+    out = S.sample(model, ds)
+    assert len(out) == min(4, len(ds)) and all(o.shape[0] == 6 and o.shape[2] == 8 for o in out)
+    assert all(bool(torch.isfinite(torch.from_numpy(o)).all()) and float(abs(o).max()) <= 3.1416 for o in out)
+    # activations of ~1e6 in the FFN of the decoder layer: beyond the fp16 range (not beyond bf16's)
+    with torch.no_grad():
+        model.decoder.layer[0].intermediate.dense.weight.mul_(3.0e4)
+        model.decoder.layer[0].output.dense.weight.mul_(1.0e-4)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out2 = S.sample(model, ds)
+    assert any("bf16x6" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert all(bool(torch.isfinite(torch.from_numpy(o)).all()) for o in out2)
