@@ -2,6 +2,8 @@
 //     out[M,N] = act(A[M,K] . B[N,K]^T + bias)         (A, B given K-contiguous or K-major)
 // Each fp32 operand x is split on the fly into bf16 terms x = x0 + x1 (+ x2) (xi = rne_bf16 of the
 // running residual) and the product is rebuilt from the significant cross terms:
+//     TERMS = 1:  a0*b0                                         (plain bf16 products, ~2^-8: what the reference's train
+//                                                                scripts select with set_float32_matmul_precision("medium"))
 //     TERMS = 3:  a0*b0 + a0*b1 + a1*b0                         (error ~2^-17 per product)
 //     TERMS = 6:  + a0*b2 + a2*b0 + a1*b1                       (error ~2^-24: fp32 grade)
 // v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so the 3-/6-term products cost
@@ -179,7 +181,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
                                                 int M, int N, int K_total, int tiles_m, int tiles_n, int k_chunk,
                                                 int bx, int by, int ny, float* __restrict__ colsum_out, int accumulate,
                                                 float* __restrict__ absmax = nullptr, float out_scale = 1.0f) {
-    constexpr int NBUF = NS == 2 ? 2 : 1;
+    constexpr int NBUF = NS <= 2 ? 2 : 1;
     constexpr int BM = WM * 64, BN = WN * 32 * TN, NT = WM * WN * 64;   // (BN shadows the file-scope 128)
     constexpr int A_BYTES = BM * ROW_B, B_BYTES = BN * ROW_B;
     constexpr int BUF_BYTES = NS * (A_BYTES + B_BYTES);  // per buffer: A parts, then B parts
@@ -298,13 +300,15 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
                     // smallest terms first
-                    if (NS == 3) {
+                    if constexpr (NS == 3) {
                         acc[m][n] = mma16(fa[1][m], fb[1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[0][m], fb[NS - 1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[NS - 1][m], fb[0][n], acc[m][n]);
                     }
-                    acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
-                    acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    if constexpr (NS >= 2) {
+                        acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    }
                     acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                 }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
@@ -563,13 +567,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    if (NS == 3) {
+                    if constexpr (NS == 3) {
                         acc[m][n] = mma16(fa[1][m], fb[1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[0][m], fb[NS - 1][n], acc[m][n]);
                         acc[m][n] = mma16(fa[NS - 1][m], fb[0][n], acc[m][n]);
                     }
-                    acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
-                    acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    if constexpr (NS >= 2) {
+                        acc[m][n] = mma16(fa[0][m], fb[1][n], acc[m][n]);
+                        acc[m][n] = mma16(fa[1][m], fb[0][n], acc[m][n]);
+                    }
                     acc[m][n] = mma16(fa[0][m], fb[0][n], acc[m][n]);
                 }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
@@ -857,9 +863,13 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
             if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)
                 return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
         }
+        if constexpr (NS == 1) {   // single-product form: the interleaved-staging 256x256 kernel from 160 tiles upwards
+            if (N % BT == 0 && ldb == K && g_tile_pref >= 3 && (int64_t)((M + BT - 1) / BT) * (N / BT) >= 160)
+                return launch256<NS, ACT, 2, 4, 2, true, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
+        }
         if (N % BT == 0 && ldb == K && g_tile_pref >= 1 &&
             (int64_t)((M + BT - 1) / BT) * (N / BT) >= 256)   // enough 256x256 tiles to fill the 256 CUs
-            return launch256<NS, ACT, 2, 4, (NS == 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
+            return launch256<NS, ACT, 2, 4, (NS <= 2 ? 2 : 1), false, E>(A, lda, B, bias, out, ldc, M, N, K, epi, s);
     }
     // general kernel, three tile forms: 1 = 256x128 (8 waves, one workgroup per CU: 96 KB of LDS), 2 = 128x128 (4 waves,
     // two per CU), 3 = 128x128 on 8 waves (each 64x32; forward and input-gradient layouts of the 2-term kernels).  Both are bound by the latency of a workgroup's own k-step chain at these sizes, so the choice is a
@@ -873,7 +883,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     if (form != 1 && form != 2 && form != 3) {
         const int64_t g256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), g128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
         const int64_t cus = e3d_cu_count();
-        if (NS != 2) form = g256 < 128 && !A_KMAJ && !B_KMAJ ? 2 : 1;       // 3-term kernels: as measured in round 1
+        if (NS == 3) form = g256 < 128 && !A_KMAJ && !B_KMAJ ? 2 : 1;       // 3-term kernels: as measured in round 1
         else if (A_KMAJ && B_KMAJ) form = 1;                                // weight gradients (split-K over one resident round): +4 %
         else if (A_KMAJ) form = g128 <= cus ? 2 : (g256 <= cus ? 1 : (45 * ((g128 + 2 * cus - 1) / (2 * cus)) < 37 * ((g256 + cus - 1) / cus) ? 2 : 1));
         // forward / input-gradient layouts: the 8-wave 128x128 form (3) against the 256x128 form (1) by rounds of one
@@ -881,7 +891,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         // against 32.5 (4-wave 128x128) / 36.9, N = 2304 70 against 81; M = 8192: form 1 by 4 %)
         else form = 25 * ((g128 + cus - 1) / cus) <= 38 * ((g256 + cus - 1) / cus) ? 3 : 1;
     }
-    if constexpr (NS == 2 && !A_KMAJ) {
+    if constexpr (NS <= 2 && !A_KMAJ) {
         // form 3: the 128x128 tile on EIGHT waves (2 x 4, each 64x32): two waves per SIMD cover each other's staging.
         // (The same form with k-tiles of 64 -- half the k-steps, 128 KB of LDS -- was built and measured: 27.3 against
         // 26.6 us at M = 4096, N = K = 768, bit-identical results; a 12-workgroup launch takes 23.5 us either way, so
@@ -899,7 +909,7 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
                    int M, int N, int K, Epi epi, hipStream_t s) {
     constexpr int BM = WM * 64, BNt = WN * 32 * TN;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BNt - 1) / BNt;
-    constexpr int NBUF = NS == 2 ? 2 : 1;
+    constexpr int NBUF = NS <= 2 ? 2 : 1;
     size_t lds = (size_t)NBUF * NS * (BM + BNt) * ROW_B;
     // A grid that fits the chip in one round at one workgroup per CU should run that way: two 128x128 workgroups fit a
     // CU's LDS, and the dispatcher does pair them up while other CUs stay empty (a workgroup alone on its CU ~29 us,
@@ -992,7 +1002,8 @@ static int gemm_split_general(const float* A, int64_t lda, int a_kmajor, const f
     E3D_REQUIRE(out_scale == 1.0f || !(a_kmajor && b_kmajor), "gemm_split: out_scale is not available for the split-K layout");
     E3D_REQUIRE(A && B && out, "gemm_split: null pointer");
     E3D_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_split: bad shape M=%d N=%d K=%d", M, N, K);
-    E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "gemm_split: terms must be 3, 6 or 19 (got %d)", terms);
+    E3D_REQUIRE(terms == E3D_TERMS_BF16 || terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3,
+                "gemm_split: terms must be 1, 3, 6 or 19 (got %d)", terms);
     E3D_REQUIRE(ldc >= N, "gemm_split: ldc=%lld < N=%d", (long long)ldc, N);
     if (!a_kmajor) E3D_REQUIRE(lda >= K && lda % 4 == 0 && K % BK == 0 && ((uintptr_t)A % 16) == 0,
                                "gemm_split: K-contiguous A needs K%%32==0, lda%%4==0, 16B alignment (K=%d lda=%lld)", K, (long long)lda);
@@ -1003,6 +1014,7 @@ static int gemm_split_general(const float* A, int64_t lda, int a_kmajor, const f
     hipStream_t s = (hipStream_t)stream;
     E3D_REQUIRE(!absmax || (!(a_kmajor && b_kmajor) && act == E3D_ACT_NONE),
                 "gemm_split: out_absmax exists for act = none and not for the split-K (weight-gradient) layout");
+    if (terms == E3D_TERMS_BF16) return dispatch<1, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     if (terms == 3) return dispatch<2, __bf16>(act, a_kmajor != 0, b_kmajor != 0, A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     if (terms == E3D_TERMS_F16X3) {
         // fp16 terms exist for the forward layout; a K-major operand (training GEMMs) runs the fp32-grade bf16x6 form
@@ -1025,7 +1037,8 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
     E3D_REQUIRE(dz && x && dw && count >= 1 && count <= 64, "gemm_wgrad_grouped: 1..64 problems (count=%d)", count);
     E3D_REQUIRE(M > 0 && N > 0 && K > 0 && ldz >= N && ldx >= K, "gemm_wgrad_grouped: bad shape N=%d K=%d M=%d ldz=%lld ldx=%lld",
                 N, K, M, (long long)ldz, (long long)ldx);
-    E3D_REQUIRE(terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3, "gemm_wgrad_grouped: terms must be 3, 6 or 19 (got %d)", terms);
+    E3D_REQUIRE(terms == E3D_TERMS_BF16 || terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3,
+                "gemm_wgrad_grouped: terms must be 1, 3, 6 or 19 (got %d)", terms);
     WgradGroup g;
     for (int p = 0; p < 64; ++p) {
         const int q = p < count ? p : 0;
@@ -1037,7 +1050,12 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
     E3D_REQUIRE((int64_t)tiles_m * tiles_n * count < (1ll << 30), "gemm_wgrad_grouped: too many tiles");
     const dim3 grid(tiles_m * tiles_n * count), block(512);
     hipStream_t s = (hipStream_t)stream;
-    if (terms == 3) {
+    if (terms == E3D_TERMS_BF16) {
+        const size_t lds = (size_t)2 * 1 * (256 + 128) * ROW_B;
+        static std::atomic<uint64_t> lds_ok{0};
+        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<1>, lds);
+        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<1>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+    } else if (terms == 3) {
         const size_t lds = (size_t)2 * 2 * (256 + 128) * ROW_B;
         static std::atomic<uint64_t> lds_ok{0};
         e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<2>, lds);

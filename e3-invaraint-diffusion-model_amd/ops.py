@@ -170,7 +170,11 @@ def absmax(x, target=None):
 # "f16x3" = 2 fp16 terms (11 + 11 bits), 3 cross products: fp32-grade accuracy at the cost of bf16x3 for operands
 # inside the fp16 range (|x| < 65504 -- larger values give inf/NaN, loudly; include/e3d_hip.h E3D_TERMS_F16X3);
 # forward GEMMs and the cooperative attention kernel, every other path of that mode runs bf16x6 / fp32 kernels.
-GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6, "f16x3": 19}
+# "bf16" = plain bf16 products (operands rounded to bf16, ONE MFMA per product, fp32 accumulate: ~2^-8 per product) -- the
+# precision the reference's TRAIN scripts select (torch.set_float32_matmul_precision("medium"),
+# structure_model/train_model.py:120).  GEMMs only (the attention kernels then run bf16x3), opt-in through
+# E3D_TRAIN_ARITHMETIC=bf16 / ops.arithmetic("bf16"); never an inference default: it is 1e-2-grade, not 1e-4.
+GEMM_MODES = {"f32": 0, "bf16x3": 3, "bf16x6": 6, "f16x3": 19, "bf16": 1}
 GEMM_MODE = os.environ.get("E3D_GEMM_MODE", "f16x3")   # inference default: fp32 grade at bf16x3 speed
 if GEMM_MODE not in GEMM_MODES:
     raise ValueError(f"E3D_GEMM_MODE must be one of {sorted(GEMM_MODES)}, got {GEMM_MODE!r}")
@@ -305,6 +309,8 @@ class arithmetic:
 
 
 ATTN_MODE = os.environ.get("E3D_ATTN_MODE", GEMM_MODE)   # same choices and meaning as GEMM_MODE
+if ATTN_MODE == "bf16":
+    ATTN_MODE = "bf16x3"
 if ATTN_MODE not in GEMM_MODES:
     raise ValueError(f"E3D_ATTN_MODE must be one of {sorted(GEMM_MODES)}, got {ATTN_MODE!r}")
 
@@ -313,6 +319,8 @@ def set_attn_mode(mode):
     global ATTN_MODE
     if mode not in GEMM_MODES:
         raise ValueError(f"attention mode must be one of {sorted(GEMM_MODES)}, got {mode!r}")
+    if mode == "bf16":      # the single-product form exists for the GEMMs only
+        mode = "bf16x3"
     prev, ATTN_MODE = ATTN_MODE, mode
     return prev
 

@@ -78,7 +78,9 @@ class BestCheckpoint:
 # The reference trains with torch.set_float32_matmul_precision("medium") (structure_model/train_model.py:120,
 # sequence_model/train_model.py:114): bf16 products.  bf16x3 is 500x finer per product and is the arithmetic every
 # backward kernel of this package exists in; the inference default (f16x3) has forward kernels only.
-TRAIN_ARITHMETIC = "bf16x3"
+# E3D_TRAIN_ARITHMETIC=bf16 (opt-in): the reference's own training precision -- plain bf16 products in every GEMM (forward,
+# input and weight gradients), bf16x3 in the attention kernels; ~1e-2-grade gradients instead of ~1e-4-grade.
+TRAIN_ARITHMETIC = os.environ.get("E3D_TRAIN_ARITHMETIC", "bf16x3")
 DEFER_WEIGHT_GRADS = os.environ.get("E3D_DEFER_WGRAD", "1") == "1"   # autograd.deferred_weight_grads in the step
 
 

@@ -33,6 +33,9 @@ extern "C" {
  *                bf16x3 -- for operands inside the fp16 range: |x| < 65504 (larger values become inf, i.e. the result is
  *                NaN/inf, never silently wrong), elements below 2^-14 carry an ABSOLUTE error of 2^-25.  Forward
  *                (K-contiguous) GEMM layout and the cooperative attention kernel; other paths run bf16x6. */
+#define E3D_TERMS_BF16 1   /* plain bf16 products (RNE operands, ~2^-8), fp32 accumulate: the reference's TRAINING precision
+                            * (torch.set_float32_matmul_precision("medium"), structure_model/train_model.py:120); GEMM entry
+                            * points only, opt-in (E3D_TRAIN_ARITHMETIC=bf16) -- never an inference default */
 #define E3D_TERMS_BF16X3 3
 #define E3D_TERMS_BF16X6 6
 #define E3D_TERMS_F16X3 19

@@ -33,7 +33,7 @@ def Fm(pkg):
     return functional
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-5), ("bf16x3", 1e-4), ("f32", 1e-5)])
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 1e-5), ("bf16x3", 1e-4), ("f32", 1e-5), ("bf16", 2e-2)])   # bf16: plain bf16 products, the reference's training precision (opt-in)
 @pytest.mark.parametrize("M,N,K,act", [(96, 256, 128, 0), (300, 768, 1024, 1), (64, 1536, 256, 2), (4096, 768, 768, 0)])
 def test_linear_backward(pkg, hip, Fm, M, N, K, act, mode, tol):
     x, w, b = torch.randn(M, K, generator=g(1)), torch.randn(N, K, generator=g(2)) / math.sqrt(K), torch.randn(N, generator=g(3))
@@ -52,10 +52,10 @@ def test_linear_backward(pkg, hip, Fm, M, N, K, act, mode, tol):
     assert rel_err(out, y.float()) < tol
     assert rel_err(xd.grad, xr.grad.float()) < tol
     assert rel_err(wd.grad, wr.grad.float()) < tol
-    assert rel_err(bd.grad, br.grad.float()) < 1e-5
+    assert rel_err(bd.grad, br.grad.float()) < (1e-5 if mode != "bf16" else tol)   # (through act'(z): z carries the products' error)
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 1e-5)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 1e-5), ("bf16", 2e-2)])
 @pytest.mark.parametrize("N,K,M,count", [(768, 768, 4096, 5), (300, 160, 1000, 3), (2304, 768, 515, 2), (64, 1024, 96, 64)])
 def test_grouped_weight_gradients(pkg, hip, N, K, M, count, mode, tol):
     """e3d_gemm_wgrad_grouped_f32_split: dW_p = dz_p^T x_p and db_p = column sums of dz_p for ``count`` layers of one
@@ -276,7 +276,7 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
     ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     loss_ref = loss_ref_fn(ref_sd)
     loss_ref.backward()
-    assert loss_dev.item() == pytest.approx(loss_ref.item(), rel=2e-4)
+    assert loss_dev.item() == pytest.approx(loss_ref.item(), rel=2e-4 if tol < 1e-2 else 2e-2)   # (plain-bf16 mode: 1e-2 grade)
     worst = {}
     # key biases have an exactly-zero gradient (softmax is invariant to a per-query shift of all
     # scores), so their "reference" gradient is rounding noise: floor every denominator at 1e-3 of
@@ -298,7 +298,7 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
 
 
 @pytest.mark.parametrize("defer", [False, True, "staged"])
-@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4)])   # measured on MI355X: 4.0e-6 / 4.1e-5
+@pytest.mark.parametrize("mode,tol", [("bf16x6", 2e-5), ("bf16x3", 2e-4), ("bf16", 1e-1)])   # measured on MI355X: 4.0e-6 / 4.1e-5 / (printed)
 def test_structure_training_step_gradients_match_oracle(pkg, hip, mode, tol, defer, capsys):
     """Whole structure model, loss of the reference (wrapped L1 x4 + smooth-L1 x4), every parameter
     gradient against CPU autograd of the oracle."""

@@ -24,7 +24,7 @@ DEV = "cuda:0"
 
 
 def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2, device=DEV, ddp=False, layers=None,
-        seed=0):
+        seed=0, arithmetic=None):
     """One GPU's training step of BASELINE config 2 (structure, B=32) / config 4 (sequence, B=64): forward + loss +
     backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict.
     ``ddp``: the step of ``training.fit`` under an initialised process group (BASELINE config 4: one rank per GPU,
@@ -81,7 +81,7 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         pkg.training.clip_and_step(params, optim, 1.0)      # as training.fit does
         return loss
 
-    with pkg.ops.arithmetic(pkg.training.TRAIN_ARITHMETIC):   # bf16x3 unless E3D_GEMM_MODE says otherwise
+    with pkg.ops.arithmetic(arithmetic or pkg.training.TRAIN_ARITHMETIC):   # bf16x3 unless E3D_GEMM_MODE says otherwise
         mode = pkg.ops.GEMM_MODE
         for _ in range(warmup):
             step()
@@ -121,8 +121,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
+    ap.add_argument("--arithmetic", default=None, help="bf16x3 (default) | bf16x6 | bf16 = plain bf16 products, the reference's own training precision")
     args = ap.parse_args()
-    r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout)
+    r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout, arithmetic=args.arithmetic)
     print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} layers={r['layers']} params={r['params_M']:.1f}M "
           f"gemm_mode={r['arithmetic']} dropout={r['dropout']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
           f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB)", flush=True)
