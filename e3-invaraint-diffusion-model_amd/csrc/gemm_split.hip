@@ -213,6 +213,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
+    f32x4 ra1[Stager<BM, A_KMAJ, NT>::NV], rb1[Stager<BN, B_KMAJ, NT>::NV];   // second staging set (PIPE): odd k-tiles
     constexpr bool CS = A_KMAJ && B_KMAJ;          // row sums of A over k ride along (cheap: 3 adds per staged item)
     float cs[Stager<BM, A_KMAJ, NT>::NV];
 #pragma unroll
@@ -235,18 +236,34 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     // that item's global load for tile t+2; the last steps re-stage the last tile into the buffer nobody reads).
     constexpr bool PIPE = NBUF == 2;
     constexpr int NA_ = Stager<BM, A_KMAJ, NT>::NV, NB_ = Stager<BN, B_KMAJ, NT>::NV;
-    if (PIPE) {
+    // DEEP: two staging register sets (below) for the K-contiguous layouts; the K-major layouts (4 dword loads per item)
+    // measured 12 % SLOWER with twice the loads in flight (weight-gradient probe 1770 -> 1986 us) and keep one set
+    constexpr bool DEEP = PIPE && !A_KMAJ && !B_KMAJ;
+    if (DEEP) {
+        const int k1 = k_begin + (nk > 1 ? BK : 0), k2 = k_begin + (nk > 2 ? 2 : (nk > 1 ? 1 : 0)) * BK;
+        sa.load(ra1, k1, K);
+        sb.load(rb1, k1, K);
+        sa.load(ra, k2, K);
+        sb.load(rb, k2, K);
+    } else if (PIPE) {
         const int k1 = k_begin + (nk > 1 ? BK : 0);
         sa.load(ra, k1, K);
         sb.load(rb, k1, K);
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    // Staging distance (DEEP): TWO register sets -- tile t lives in set t & 1; iteration kt stores tile kt + 1 from its set
+    // into the other LDS buffer and re-issues that set's global loads for tile kt + 3, while the other set's loads (tile
+    // kt + 2, issued an iteration ago) are still in flight.  With one set (rounds 1-2) a load had to arrive within ONE
+    // k-step: at M = 4096 the k-step was its latency (the same launch with a third of the MFMAs, terms = 1, was only 10 %
+    // faster), i.e. a CU never had more than ~32 KB in flight.
+    auto k_step = [&](int kt, f32x4 (&xa)[NA_], f32x4 (&xb)[NB_]) {
         const bool more = kt + 1 < nk;
         if (!PIPE && more) {
-            sa.load(ra, k_begin + (kt + 1) * BK, K);
-            sb.load(rb, k_begin + (kt + 1) * BK, K);
+            sa.load(xa, k_begin + (kt + 1) * BK, K);
+            sb.load(xb, k_begin + (kt + 1) * BK, K);
         }
-        const int k2 = k_begin + (kt + 2 < nk ? kt + 2 : nk - 1) * BK;
+        // the set just stored (tile kt + 1) is re-loaded with tile kt + 3 (DEEP: a load has TWO k-steps to arrive) / kt + 2
+        constexpr int AHEAD = DEEP ? 3 : 2;
+        const int k2 = k_begin + (kt + AHEAD < nk ? kt + AHEAD : nk - 1) * BK;
         unsigned char* nxt = smem_raw + (cur ^ 1) * BUF_BYTES;
         const unsigned char* ab = smem_raw + cur * BUF_BYTES;
         const unsigned char* bb = smem_raw + cur * BUF_BYTES + NS * A_BYTES;
@@ -286,15 +303,15 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
                     for (int i = 0; i < NA_; ++i)
                         if (i * 4 / NA_ == g) {
-                            if (CS) cs[i] += sa.masked_sum(i, ra[i], k_begin + (kt + 1) * BK, K);
-                            sa.template store_item<NS, E>(i, ra[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
-                            sa.load_item(i, ra[i], k2, K);
+                            if (CS) cs[i] += sa.masked_sum(i, xa[i], k_begin + (kt + 1) * BK, K);
+                            sa.template store_item<NS, E>(i, xa[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
+                            sa.load_item(i, xa[i], k2, K);
                         }
 #pragma unroll
                     for (int i = 0; i < NB_; ++i)
                         if (i * 4 / NB_ == g) {
-                            sb.template store_item<NS, E>(i, rb[i], nxt + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
-                            sb.load_item(i, rb[i], k2, K);
+                            sb.template store_item<NS, E>(i, xb[i], nxt + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
+                            sb.load_item(i, xb[i], k2, K);
                         }
                 }
 #pragma unroll
@@ -322,15 +339,23 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
             if (more) {
                 if (CS) {
 #pragma unroll
-                    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, ra[i], k_begin + (kt + 1) * BK, K);
+                    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, xa[i], k_begin + (kt + 1) * BK, K);
                 }
-                sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
-                sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
+                sa.template store<NS, E>(xa, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
+                sb.template store<NS, E>(xb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
             }
             __syncthreads();
         }
+        };
+    for (int kt = 0; kt < nk; kt += 2) {
+        if constexpr (DEEP) {
+            k_step(kt, ra1, rb1);
+            if (kt + 1 < nk) k_step(kt + 1, ra, rb);
+        } else {
+            k_step(kt, ra, rb);
+            if (kt + 1 < nk) k_step(kt + 1, ra, rb);
+        }
     }
-
     unsigned amax = 0;   // largest |out| written by this lane (absmax != nullptr: see e3d_absmax_accum)
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
