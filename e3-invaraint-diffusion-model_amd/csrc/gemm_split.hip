@@ -19,7 +19,9 @@
 //     dgrad     dx = dy W  : A = dy [M,K'] K-contiguous, B = W as [K'][N'] -> "K-major"
 //     wgrad     dW = dy^T x: A = dy as [K'][M'] K-major,  B = x as [K'][N'] K-major
 // A K-major operand is read with one dword per lane (lanes along the contiguous output index, so
-// every k-row is a coalesced 256-byte segment) and transposed for free by the LDS write.
+// every k-row is a coalesced 256-byte segment) and transposed for free by the LDS write; when BOTH
+// are K-major and come in whole quads (the weight gradients) StagerT reads float4s instead and the
+// transposition moves to the fragment reads (ds_read_b64_tr_b16).
 #include <type_traits>
 
 #include "e3d_common.h"
@@ -164,6 +166,86 @@ struct Stager {
     }
 };
 
+// Transposing staging of a K-major operand (the weight-gradient layout, TR): an item is a float4 along the CONTIGUOUS
+// output index (4 rows of the operand) for ONE k -- a quarter of the load instructions of the dword scheme above, each
+// 16 bytes wide (a wave reads whole 1-KB / 512-byte k-rows).  The image is kept in the memory's own orientation,
+// [k][row] bf16 (pitch = 2 ROWS bytes: the same bytes per plane as the [row][k] image), and the MFMA fragments -- 8 k
+// values per lane -- are read with ds_read_b64_tr_b16, gfx950's transposing LDS read (two per fragment; k then runs in
+// the order 4 half + (j & 3) + 8 (j >> 2) inside a 16-block: the same for both operands, so the contraction is intact).
+// 32-byte units (16 rows of one k) are XOR-ed by 2 (k & 3): the 4 k-rows x 2 units a 32-lane half of a transposing read
+// touches then fall into 8 distinct 8-bank windows, and a wave's 8-byte writes still cover whole k-rows.
+template <int ROWS, int NT>
+struct StagerT {
+    static constexpr int NV = ROWS * 8 / NT;
+    static constexpr int PITCH = ROWS * 2, Q = ROWS / 4, KSTEP = NT / Q;   // KSTEP: k-rows one pass of the workgroup covers
+    static_assert(KSTEP * NV == 32, "a k-tile is 32 k-rows");
+    const float* src;       // operand base + this thread's 4 rows (clamped at the edge: those outputs are discarded)
+    int64_t ld;
+    int kk0, n4;
+
+    __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int row_limit, int tid) {
+        ld = ld_;
+        n4 = tid % Q;
+        kk0 = tid / Q;
+        const int gr = min(row0 + 4 * n4, row_limit - 4);     // row_limit % 4 == 0 (checked by the launcher)
+        src = base + gr;
+    }
+    __device__ __forceinline__ int kk(int i) const { return kk0 + KSTEP * i; }
+    __device__ __forceinline__ int off(int i) const {
+        const int k = kk(i);
+        return k * PITCH + (((n4 >> 2) ^ (2 * (k & 3))) << 5) + (n4 & 3) * 8;
+    }
+    __device__ __forceinline__ void load_item(int i, f32x4& v, int k0, int K) const {
+        const int k = min(k0 + kk(i), K - 1);                 // the K tail is zeroed at store time
+        v = *reinterpret_cast<const f32x4*>(src + (int64_t)k * ld);
+    }
+    __device__ __forceinline__ void load(f32x4 (&v)[NV], int k0, int K) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) load_item(i, v[i], k0, K);
+    }
+    __device__ __forceinline__ f32x4 masked(int i, const f32x4& v, int k0, int K) const {
+        const bool in = k0 + kk(i) < K;
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = in ? v[j] : 0.f;
+        return r;
+    }
+    template <int NS, typename E>
+    __device__ __forceinline__ void store_item(int i, const f32x4& vin, unsigned char* img, int part_bytes, int k0, int K) const {
+        const f32x4 v = masked(i, vin, k0, K);
+        typename Vec<E>::x4 p[NS];
+        split4<NS, E>(v, p);
+        const int o = off(i);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(img + s * part_bytes + o) = p[s];
+    }
+    template <int NS, typename E>
+    __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned char* img, int part_bytes, int k0, int K) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) store_item<NS, E>(i, v[i], img, part_bytes, k0, K);
+    }
+    // (interface parity with Stager; the column sums of the TR form are kept per row quad by the caller)
+    __device__ __forceinline__ float masked_sum(int, const f32x4&, int, int) const { return 0.f; }
+};
+
+// Transposed fragment of a [k][row] image (StagerT): rows r0 .. r0 + 31 (lane & 31), the 16-block ks of the k-tile.
+// ``lane_off`` = tr_lane_off(PITCH, r0, lane): everything but the k-block.
+__device__ __forceinline__ int tr_lane_off(int pitch, int r0, int lane) {
+    const int q = (lane >> 2) & 3, g = (lane >> 4) & 1, half = lane >> 5;
+    return (4 * half + q) * pitch + ((((r0 >> 4) + g) ^ (2 * q)) << 5) + 8 * (lane & 3);
+}
+template <typename X8>
+__device__ __forceinline__ X8 tr_frag8(const unsigned char* img, int pitch, int lane_off, int ks) {
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) short4v* lds_p;
+    const unsigned char* p0 = img + 16 * ks * pitch + lane_off;
+    const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+    const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 8 * pitch));
+    const short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(X8, c);
+}
+
 // WM = waves along M: 4 -> 256x128 tile, 512 threads; 2 -> 128x128 tile, 256 threads (used for grids of a few
 // tiles only: it halves the padded rows of an M = 64 problem; at M = 4096 it measured 25 % slower than WM = 4).
 // WN = waves along N (64 columns each).  WN = 1 (128 x 64 tiles of two waves, three workgroups per CU, twice the grid)
@@ -174,7 +256,7 @@ struct Stager {
 // the workgroups of tile column 0 also write out-row sums of A over the reduction index -- the bias gradient
 // sum_m dz[m][n] of a linear layer, whose weight gradient dz^T . x this layout computes -- from the values they stage
 // anyway.  ``accumulate``: out += instead of out = (a weight used twice in one backward pass).
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2, bool TR = false>
 __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const float* __restrict__ A, int64_t lda,
                                                 const float* __restrict__ Bm, int64_t ldb,
                                                 const float* __restrict__ bias, float* __restrict__ out, int64_t ldc,
@@ -199,8 +281,11 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     const int wr = wid / WN, wc = wid % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
-    Stager<BM, A_KMAJ, NT> sa;
-    Stager<BN, B_KMAJ, NT> sb;
+    static_assert(!TR || (A_KMAJ && B_KMAJ), "the transposing staging exists for the K-major x K-major layout");
+    typedef typename std::conditional<TR, StagerT<BM, NT>, Stager<BM, A_KMAJ, NT>>::type SA;
+    typedef typename std::conditional<TR, StagerT<BN, NT>, Stager<BN, B_KMAJ, NT>>::type SB;
+    SA sa;
+    SB sb;
     sa.init(A, lda, row0, M, tid);
     sb.init(Bm, ldb, col0, N, tid);
 
@@ -212,17 +297,22 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    f32x4 ra[Stager<BM, A_KMAJ, NT>::NV], rb[Stager<BN, B_KMAJ, NT>::NV];
-    f32x4 ra1[Stager<BM, A_KMAJ, NT>::NV], rb1[Stager<BN, B_KMAJ, NT>::NV];   // second staging set (PIPE): odd k-tiles
+    f32x4 ra[SA::NV], rb[SB::NV];
+    f32x4 ra1[SA::NV], rb1[SB::NV];   // second staging set (PIPE): odd k-tiles
     constexpr bool CS = A_KMAJ && B_KMAJ;          // row sums of A over k ride along (cheap: 3 adds per staged item)
-    float cs[Stager<BM, A_KMAJ, NT>::NV];
+    float cs[SA::NV];
+    f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};              // TR: an item is 4 ROWS of one k -- one sum per row of the thread's quad
 #pragma unroll
-    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] = 0.f;
+    for (int i = 0; i < SA::NV; ++i) cs[i] = 0.f;
+    auto cs_add = [&](int i, const f32x4& v, int k0) {
+        if constexpr (TR) cs4 += sa.masked(i, v, k0, K);
+        else cs[i] += sa.masked_sum(i, v, k0, K);
+    };
     sa.load(ra, k_begin, K);
     sb.load(rb, k_begin, K);
     if (CS) {
 #pragma unroll
-        for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, ra[i], k_begin, K);
+        for (int i = 0; i < SA::NV; ++i) cs_add(i, ra[i], k_begin);
     }
     sa.template store<NS, E>(ra, smem_raw, A_BYTES, k_begin, K);
     sb.template store<NS, E>(rb, smem_raw + NS * A_BYTES, B_BYTES, k_begin, K);
@@ -235,10 +325,17 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     // preceded by its share of the staging of tile t+1 (split + ds_write of a register item, then the re-issue of
     // that item's global load for tile t+2; the last steps re-stage the last tile into the buffer nobody reads).
     constexpr bool PIPE = NBUF == 2;
-    constexpr int NA_ = Stager<BM, A_KMAJ, NT>::NV, NB_ = Stager<BN, B_KMAJ, NT>::NV;
+    constexpr int NA_ = SA::NV, NB_ = SB::NV;
     // DEEP: two staging register sets (below) for the K-contiguous layouts; the K-major layouts (4 dword loads per item)
     // measured 12 % SLOWER with twice the loads in flight (weight-gradient probe 1770 -> 1986 us) and keep one set
-    constexpr bool DEEP = PIPE && !A_KMAJ && !B_KMAJ;
+    constexpr bool DEEP = PIPE && ((!A_KMAJ && !B_KMAJ) || TR);   // (TR: float4 loads, as few as the K-contiguous layouts')
+    int tr_a[2], tr_b[TN];                          // TR: per-lane offsets of the transposed fragments (m / n tile)
+    if constexpr (TR) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) tr_a[m] = tr_lane_off(2 * BM, wr * 64 + 32 * m, lane);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) tr_b[n] = tr_lane_off(2 * BN, wc * (32 * TN) + 32 * n, lane);
+    }
     if (DEEP) {
         const int k1 = k_begin + (nk > 1 ? BK : 0), k2 = k_begin + (nk > 2 ? 2 : (nk > 1 ? 1 : 0)) * BK;
         sa.load(ra1, k1, K);
@@ -288,13 +385,17 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    fa[s][m] = PREF ? fa2[ks][s][m]
-                                    : *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
+                for (int m = 0; m < 2; ++m) {
+                    if constexpr (TR) fa[s][m] = tr_frag8<typename Vec<E>::x8>(ab + s * A_BYTES, 2 * BM, tr_a[m], ks);
+                    else fa[s][m] = PREF ? fa2[ks][s][m]
+                                         : *reinterpret_cast<const typename Vec<E>::x8*>(ab + s * A_BYTES + swz_off(a_row + 32 * m, 2 * ks + half));
+                }
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    fb[s][n] = PREF ? fb2[ks][s][n]
-                                    : *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
+                for (int n = 0; n < TN; ++n) {
+                    if constexpr (TR) fb[s][n] = tr_frag8<typename Vec<E>::x8>(bb + s * B_BYTES, 2 * BN, tr_b[n], ks);
+                    else fb[s][n] = PREF ? fb2[ks][s][n]
+                                         : *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
+                }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -303,7 +404,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
 #pragma unroll
                     for (int i = 0; i < NA_; ++i)
                         if (i * 4 / NA_ == g) {
-                            if (CS) cs[i] += sa.masked_sum(i, xa[i], k_begin + (kt + 1) * BK, K);
+                            if (CS) cs_add(i, xa[i], k_begin + (kt + 1) * BK);
                             sa.template store_item<NS, E>(i, xa[i], nxt, A_BYTES, k_begin + (kt + 1) * BK, K);
                             sa.load_item(i, xa[i], k2, K);
                         }
@@ -339,7 +440,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
             if (more) {
                 if (CS) {
 #pragma unroll
-                    for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) cs[i] += sa.masked_sum(i, xa[i], k_begin + (kt + 1) * BK, K);
+                    for (int i = 0; i < SA::NV; ++i) cs_add(i, xa[i], k_begin + (kt + 1) * BK);
                 }
                 sa.template store<NS, E>(xa, smem_raw, A_BYTES, k_begin + (kt + 1) * BK, K);
                 sb.template store<NS, E>(xb, smem_raw + NS * A_BYTES, B_BYTES, k_begin + (kt + 1) * BK, K);
@@ -383,10 +484,16 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
         // 8 threads (the 4-k groups of a k-tile) hold partial sums of each row: meet in LDS, summed in a fixed order.
         // (every wave is past its last fragment read: the k loop ends with a workgroup barrier)
         float* red = reinterpret_cast<float*>(smem_raw);
+        if constexpr (TR) {   // the 8 threads that share a row quad (k-rows kk0, kk0 + 8, ...: groups of BM / 4 threads)
+            static_assert(SA::KSTEP == 8, "8 partial sums per row, as in the dword scheme");
 #pragma unroll
-        for (int i = 0; i < Stager<BM, A_KMAJ, NT>::NV; ++i) {
-            const int f = tid + NT * i;
-            red[(f / BM) * BM + f % BM] = cs[i];
+            for (int j = 0; j < 4; ++j) red[sa.kk0 * BM + 4 * sa.n4 + j] = cs4[j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < SA::NV; ++i) {
+                const int f = tid + NT * i;
+                red[(f / BM) * BM + f % BM] = cs[i];
+            }
         }
         __syncthreads();
         if (tid < BM && row0 + tid < M) {
@@ -400,7 +507,7 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     }
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2, bool TR = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ Bm, int64_t ldb,
                                                          const float* __restrict__ bias,
@@ -408,7 +515,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_split_kernel(const float* _
                                                          int N, int K_total, int tiles_m, int tiles_n,
                                                          int k_chunk, float* __restrict__ absmax, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
+    gemm_split_body<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN, TR>(smem_raw, A, lda, Bm, ldb, bias, out, ldc, M, N, K_total, tiles_m,
                                                         tiles_n, k_chunk, xcd_remap(blockIdx.x, tiles_m * tiles_n),
                                                         blockIdx.y, gridDim.y, nullptr, 0, absmax, out_scale);
 }
@@ -427,16 +534,16 @@ struct WgradGroup {
     unsigned long long accumulate;   // bit p: dW_p / db_p += (the weight already holds a gradient)
 };
 
-template <int NS>
+template <int NS, bool TR>
 __global__ __launch_bounds__(512) void gemm_wgrad_grouped_kernel(const WgradGroup g, int64_t ldz, int64_t ldx, int N, int K,
                                                                  int M, int tiles_m, int tiles_n, int count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tiles = tiles_m * tiles_n;
     const int lid = xcd_remap(blockIdx.x, tiles * count);
     const int p = lid / tiles;
-    gemm_split_body<NS, E3D_ACT_NONE, true, true, 4, 2, __bf16>(smem_raw, g.dz[p], ldz, g.x[p], ldx, nullptr, g.dw[p], K, N,
-                                                                 K, M, tiles_m, tiles_n, M, lid - p * tiles, 0, 1, g.db[p],
-                                                                 (int)((g.accumulate >> p) & 1));
+    gemm_split_body<NS, E3D_ACT_NONE, true, true, 4, 2, __bf16, 2, TR>(smem_raw, g.dz[p], ldz, g.x[p], ldx, nullptr, g.dw[p], K,
+                                                                        N, K, M, tiles_m, tiles_n, M, lid - p * tiles, 0, 1,
+                                                                        g.db[p], (int)((g.accumulate >> p) & 1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -854,7 +961,7 @@ int launch256(const float* A, int64_t lda, const float* W, const float* bias, fl
     return e3d_launch_status("e3d_gemm_f32_split (128x64 wave tiles)");
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN = 2, bool TR = false>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, Epi epi, hipStream_t s);
 
@@ -926,10 +1033,15 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     }
     if (form == 3) form = 2;
     if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+    if constexpr (A_KMAJ && B_KMAJ) {   // weight-gradient layout: the transposing staging when both operands come in whole quads
+        static const bool tr_on = !getenv("E3D_WGRAD_TR") || atoi(getenv("E3D_WGRAD_TR")) != 0;
+        if (tr_on && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0)
+            return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E, 2, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+    }
     return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
 }
 
-template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN>
+template <int NS, int ACT, bool A_KMAJ, bool B_KMAJ, int WM, int WN, typename E, int TN, bool TR>
 int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* out, int64_t ldc,
                    int M, int N, int K, Epi epi, hipStream_t s) {
     constexpr int BM = WM * 64, BNt = WN * 32 * TN;
@@ -942,7 +1054,7 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
     static const bool spread = !getenv("E3D_GEMM_SPREAD") || atoi(getenv("E3D_GEMM_SPREAD")) != 0;
     if (spread && BM * BNt == 128 * 128 && (int64_t)tiles_m * tiles_n <= e3d_cu_count() && lds < (size_t)84 * 1024) lds = (size_t)84 * 1024;
     static std::atomic<uint64_t> lds_ok{0};
-    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>, (size_t)84 * 1024 > lds ? (size_t)84 * 1024 : lds);
+    e3d_allow_lds(lds_ok, gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN, TR>, (size_t)84 * 1024 > lds ? (size_t)84 * 1024 : lds);
     // split-K only for the K-major x K-major (weight-gradient) layout: few tiles, K = token count; one round of
     // resident workgroups (more slices only add atomics: measured in round 1)
     int splits = 1;
@@ -964,7 +1076,7 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
             return (int)e;
         }
     }
-    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN>), dim3(tiles_m * tiles_n, splits),
+    hipLaunchKernelGGL((gemm_split_kernel<NS, ACT, A_KMAJ, B_KMAJ, WM, WN, E, TN, TR>), dim3(tiles_m * tiles_n, splits),
                        dim3(WM * WN * 64), lds, s, A, lda, B, ldb, bias, out, ldc, M, N, K, tiles_m, tiles_n, k_chunk,
                        splits > 1 ? nullptr : epi.absmax, epi.scale);
     return e3d_launch_status("e3d_gemm_f32_split");
@@ -1071,25 +1183,31 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
         g.dz[p] = dz[q]; g.x[p] = x[q]; g.dw[p] = dw[q]; g.db[p] = db ? db[q] : nullptr;
     }
     g.accumulate = accumulate_bits;
+    // transposing staging (float4 loads along the contiguous index, ds_read_b64_tr_b16 fragments): whole quads only
+    static const bool tr_on = !getenv("E3D_WGRAD_TR") || atoi(getenv("E3D_WGRAD_TR")) != 0;
+    bool tr = tr_on && N % 4 == 0 && K % 4 == 0 && ldz % 4 == 0 && ldx % 4 == 0;
+    for (int p = 0; p < count && tr; ++p) tr = ((uintptr_t)dz[p] % 16) == 0 && ((uintptr_t)x[p] % 16) == 0;
     const int tiles_m = (N + 255) / 256, tiles_n = (K + 127) / 128;
     E3D_REQUIRE((int64_t)tiles_m * tiles_n * count < (1ll << 30), "gemm_wgrad_grouped: too many tiles");
     const dim3 grid(tiles_m * tiles_n * count), block(512);
     hipStream_t s = (hipStream_t)stream;
+    auto go = [&](auto kern, size_t lds, std::atomic<uint64_t>& lds_ok) {
+        e3d_allow_lds(lds_ok, kern, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+    };
+    static std::atomic<uint64_t> ok1{0}, ok1t{0}, ok2{0}, ok2t{0}, ok3{0}, ok3t{0};
     if (terms == E3D_TERMS_BF16) {
         const size_t lds = (size_t)2 * 1 * (256 + 128) * ROW_B;
-        static std::atomic<uint64_t> lds_ok{0};
-        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<1>, lds);
-        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<1>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+        if (tr) go(gemm_wgrad_grouped_kernel<1, true>, lds, ok1t);
+        else go(gemm_wgrad_grouped_kernel<1, false>, lds, ok1);
     } else if (terms == 3) {
         const size_t lds = (size_t)2 * 2 * (256 + 128) * ROW_B;
-        static std::atomic<uint64_t> lds_ok{0};
-        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<2>, lds);
-        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<2>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+        if (tr) go(gemm_wgrad_grouped_kernel<2, true>, lds, ok2t);
+        else go(gemm_wgrad_grouped_kernel<2, false>, lds, ok2);
     } else {   // fp32-grade: three bf16 terms, six products (the K-major layouts have no fp16 form)
         const size_t lds = (size_t)1 * 3 * (256 + 128) * ROW_B;
-        static std::atomic<uint64_t> lds_ok{0};
-        e3d_allow_lds(lds_ok, gemm_wgrad_grouped_kernel<3>, lds);
-        hipLaunchKernelGGL(gemm_wgrad_grouped_kernel<3>, grid, block, lds, s, g, ldz, ldx, N, K, M, tiles_m, tiles_n, count);
+        if (tr) go(gemm_wgrad_grouped_kernel<3, true>, lds, ok3t);
+        else go(gemm_wgrad_grouped_kernel<3, false>, lds, ok3);
     }
     return e3d_launch_status("e3d_gemm_wgrad_grouped_f32_split");
 }

@@ -56,12 +56,15 @@ def test_linear_backward(pkg, hip, Fm, M, N, K, act, mode, tol):
 
 
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 1e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("N,K,M,count", [(768, 768, 4096, 5), (300, 160, 1000, 3), (2304, 768, 515, 2), (64, 1024, 96, 64)])
+@pytest.mark.parametrize("N,K,M,count", [(768, 768, 4096, 5), (300, 160, 1000, 3), (2304, 768, 515, 2), (64, 1024, 96, 64),
+                                         (302, 162, 1000, 3)])
 def test_grouped_weight_gradients(pkg, hip, N, K, M, count, mode, tol):
     """e3d_gemm_wgrad_grouped_f32_split: dW_p = dz_p^T x_p and db_p = column sums of dz_p for ``count`` layers of one
     shape in one launch, against fp64: ragged tiles (N, K not multiples of the 256x128 tile), a token count that is
     not a multiple of the k-step, dz given as a column block of a wider matrix (packed QKV), the accumulate bit,
-    problems without a bias, and run-to-run bit-identity (no atomics)."""
+    problems without a bias, and run-to-run bit-identity (no atomics).  Shapes in whole quads (N, K, both row strides
+    multiples of 4: every layer of the models) take the transposing staging (float4 loads, ds_read_b64_tr_b16 fragments);
+    the last case (N = 302) the dword staging."""
     import ctypes
     lib = pkg.hip.lib()
     terms = pkg.ops.GEMM_MODES[mode]

@@ -98,5 +98,34 @@ for (B, L, relkey, drop) in ((32, 128, True, 0.0), (32, 128, False, 0.0), (64, 9
                 bad += 1
                 print(f"attention backward B={B} L={L} relkey={relkey} rep {r}: error {err:.2e}", flush=True)
     print(f"attention backward (fused) B={B} L={L} relkey={relkey} drop={drop}: worst error vs the fp32-grade kernels {worst:.2e}", flush=True)
+# round 3: the grouped weight-gradient launches with the transposing staging (float4 loads, [k][row] images, two staging
+# register sets, ds_read_b64_tr_b16 fragments): bit-identical between two launches, block-wise against fp64
+import ctypes  # noqa: E402
+lib = pkg.hip.lib()
+for (N, K, M, count) in ((768, 768, 4096, 12), (2304, 768, 4096, 4), (1024, 768, 8192, 6), (768, 1024, 4000, 6)):
+    worst = 0.0
+    for r in range(max(1, reps // 2)):
+        g = torch.Generator(device=dev).manual_seed(13 * r + N)
+        dz = [torch.randn(M, N, device=dev, generator=g) for _ in range(count)]
+        x = [torch.randn(M, K, device=dev, generator=g) for _ in range(count)]
+        outs = []
+        for _ in range(2):
+            dw = [torch.empty(N, K, device=dev) for _ in range(count)]
+            db = [torch.empty(N, device=dev) for _ in range(count)]
+            arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])   # noqa: E731
+            pkg.hip.check(lib.e3d_gemm_wgrad_grouped_f32_split(arr(dz), arr(x), arr(dw), arr(db), 0, count, N, K, N, K, M, 3,
+                                                               torch.cuda.current_stream().cuda_stream), "grouped wgrad")
+            outs.append(dw + db)
+        if not all(torch.equal(a, b) for a, b in zip(*outs)):
+            bad += 1
+            print(f"grouped wgrad {N}x{K} over {M} rep {r}: NOT bit-identical between two launches", flush=True)
+        for p_ in range(0, count, 3):
+            ref = dz[p_].double().t() @ x[p_].double()
+            err = ((outs[0][p_].double() - ref).abs().view(N // 32, 32, K // 32, 32).amax((1, 3)) / ref.abs().max()).max().item()
+            worst = max(worst, err)
+            if err > 3e-5:
+                bad += 1
+                print(f"grouped wgrad {N}x{K} over {M} rep {r} problem {p_}: block error {err:.2e}", flush=True)
+    print(f"grouped wgrad dW[{N}x{K}] over {M} tokens x {count}: worst block error vs fp64 {worst:.2e}", flush=True)
 print("race screen:", "CLEAN" if bad == 0 else f"{bad} PROBLEMS")
 sys.exit(1 if bad else 0)
