@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3D_HIP_LIB", os.path.join(_HERE, "libe3d_hip.so"))   # override: kernel experiments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = c_void_p
 _SIGNATURES = {
@@ -78,6 +78,10 @@ _SIGNATURES = {
     "e3d_q_sample_wrap": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int64, _P]),
     "e3d_discrete_posterior_sample": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "e3d_discrete_q_sample": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
+    # optimizer step (ABI v3)
+    "e3d_optim_chunk_elems": (c_int, []),
+    "e3d_grad_global_norm": (c_int, [_P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
+    "e3d_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -13,13 +13,19 @@ import torch
 
 
 def adamw(params, lr, weight_decay):
-    """torch.optim.AdamW as the reference builds it (structure_model/model.py:361-366), with the single-kernel
-    ``fused`` update when every parameter lives on the GPU (the default multi-tensor path is ~10 passes over the
-    146 M parameters, ~4 ms of a 45-ms step); E3D_FUSED_ADAMW=0 keeps torch's default."""
+    """torch.optim.AdamW as the reference builds it (structure_model/model.py:361-366).  With every parameter on the GPU
+    this is ``optim.ClipAdamW``: the same optimizer (state, state_dict, hooks, schedulers) whose step -- together with the
+    gradient-norm clip around it, see ``clip_and_step`` -- runs as three HIP launches over all parameters (csrc/optim.hip)
+    instead of torch's multi-tensor passes (norm 0.2 ms + clip multiply 0.27 ms + fused update 0.98 ms for the 146 M
+    parameters of the structure model).  E3D_FUSED_ADAMW=torch: torch's own ``fused`` kernel; =0: torch's default."""
     params = list(params)
-    fused = os.environ.get("E3D_FUSED_ADAMW", "1") == "1" and params and all(p.is_cuda for p in params)
+    choice = os.environ.get("E3D_FUSED_ADAMW", "1")
+    on_gpu = bool(params) and all(p.is_cuda for p in params)
+    if choice == "1" and on_gpu:
+        from .optim import ClipAdamW
+        return ClipAdamW(params, lr=lr, weight_decay=weight_decay)
     try:
-        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True) if fused else \
+        return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=True) if (choice == "torch" and on_gpu) else \
             torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
     except (TypeError, RuntimeError):
         return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay)
@@ -37,6 +43,9 @@ def clip_and_step(params, optim, max_norm, fold=None):
     every unscaled gradient back and goes from 59 to 93 us per launch x 17 = +0.59 ms -- a net LOSS of 0.3 ms, so the
     two-call form stays the default; the folded form is kept for the comparison (tests/test_training_gpu.py pins that both
     give the same parameters)."""
+    from .optim import ClipAdamW
+    if isinstance(optim, ClipAdamW):                  # norm, clip and update in three launches (csrc/optim.hip)
+        return optim.step_clipped(max_norm)
     if fold is None:
         fold = os.environ.get("E3D_FOLD_CLIP", "0") == "1"
     grads = [p.grad for p in params if p.grad is not None]

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define E3D_ABI_VERSION 2
+#define E3D_ABI_VERSION 3
 
 /* ``terms`` of the split-operand entry points: how an fp32 operand enters the 16-bit matrix cores.
  *   3  (bf16x3): 2 bf16 terms, 3 cross products, ~2^-17 per product, fp32 exponent range;
@@ -379,6 +379,26 @@ int e3d_small_k_wgrad(const float* g, const float* x, float* dW, float* db, int 
 /* dx[M,H] = dout[M,Nout] @ W[Nout,H] (input gradient of predictor.dense2). */
 int e3d_head_linear_bwd_dx(const float* dout, const float* W, float* dx, int M, int H, int Nout,
                            void* stream);
+
+/* ---- optimizer step (ABI v3) ------------------------------------------------------------------------------------------
+ * Global-norm gradient clip + AdamW over ALL parameters in three launches: what Lightning's gradient_clip_val = 1.0
+ * (structure_model/train_model.py:99-110) and torch.optim.AdamW (structure_model/model.py:361-366,
+ * sequence_model/model.py configure_optimizers) do around every training_step.  Tensors are reached through pointer
+ * tables in DEVICE memory (``count`` entries: params / grads / exp_avg / exp_avg_sq pointers and element counts); the work
+ * unit is a chunk of e3d_optim_chunk_elems() consecutive elements of one tensor, listed by the caller in
+ * ``chunk_tensor[n_chunks]`` (table index) and ``chunk_first[n_chunks]`` (first element), both device arrays.
+ *   e3d_grad_global_norm: norm_and_clip[0] = sqrt(sum g^2) (deterministic: per-chunk partials into ``partial[n_chunks]``,
+ *     summed in a fixed order), norm_and_clip[1] = min(max_norm / (norm + 1e-6), 1) (NaN / inf propagate, as
+ *     torch.nn.utils.clip_grad_norm_ with error_if_nonfinite=False).  Gradients are NOT rewritten.
+ *   e3d_adamw_step: torch's AdamW update (decoupled weight decay, bias corrections from ``step`` >= 1) with every gradient
+ *     multiplied by norm_and_clip[1] on the way in (norm_and_clip may be NULL: no clip).  */
+int e3d_optim_chunk_elems(void);
+int e3d_grad_global_norm(const float* const* grads, const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first,
+                         int n_chunks, float max_norm, float* partial, float* norm_and_clip, void* stream);
+int e3d_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first, int n_chunks,
+                   const float* norm_and_clip, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -344,3 +344,28 @@ def test_deferred_weight_gradient_queue_reports_parameters_in_stages(pkg):
         q2.add(None, None, ws[i], None)
     q2.flush()
     assert calls == [("slice", [2, 1, 0])]
+
+
+def test_clip_adamw_on_cpu_parameters_is_torch_adamw(pkg):
+    """optim.ClipAdamW with parameters the HIP kernels do not cover (here: CPU tensors) behaves exactly as
+    clip_grad_norm_ + torch.optim.AdamW -- the host logic around the kernels (step_clipped, fallback, state layout)."""
+    from e3diff_amd.optim import ClipAdamW
+    from e3diff_amd.training import clip_and_step
+    torch.manual_seed(0)
+    base = [torch.randn(17, 5), torch.randn(33)]
+    outs = []
+    for impl in ("torch", "ours"):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        opt = torch.optim.AdamW(ps, lr=1e-2, weight_decay=0.1) if impl == "torch" else ClipAdamW(ps, lr=1e-2, weight_decay=0.1)
+        for step in range(3):
+            for i, p in enumerate(ps):
+                p.grad = torch.full_like(p, 3.0 * (i + 1) * (step + 1))
+            if impl == "torch":
+                n = torch.nn.utils.clip_grad_norm_(ps, 1.0)
+                opt.step()
+            else:
+                n = clip_and_step(ps, opt, 1.0)
+        outs.append((ps, float(n), opt.state_dict()))
+    assert outs[0][1] == outs[1][1]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert outs[0][2]["param_groups"][0].keys() == outs[1][2]["param_groups"][0].keys()

@@ -105,7 +105,8 @@ def test_clip_folded_into_the_fused_adamw_matches_clip_then_step(pkg, hip):
     """training.clip_and_step(fold=True) hands torch's fused AdamW 1 / clip_coef as ``grad_scale``: the parameters after the
     step equal those of clip_grad_norm_ + step (an ulp from g / (1/c) vs g * c), with the clip active and inactive.  (The
     folded form measured slower on MI355X and is not the default: see the function's docstring.)"""
-    from e3diff_amd.training import adamw, clip_and_step
+    from e3diff_amd.training import clip_and_step
+    adamw = lambda ps, lr, weight_decay: torch.optim.AdamW(ps, lr=lr, weight_decay=weight_decay, fused=True)   # noqa: E731
     for scale in (50.0, 1e-3):           # gradient norm far above / below max_norm = 1
         torch.manual_seed(0)
         base = [torch.randn(257, 33, device="cuda:0"), torch.randn(1000, device="cuda:0")]
@@ -163,3 +164,60 @@ def test_structure_sample_entry_point_and_its_f16x3_safety_net(pkg, hip, monkeyp
         out2 = S.sample(model, ds)
     assert any("bf16x6" in str(x.message) for x in w), [str(x.message) for x in w]
     assert all(bool(torch.isfinite(torch.from_numpy(o)).all()) for o in out2)
+
+
+def test_clip_adamw_three_launch_step_matches_torch(pkg, hip):
+    """optim.ClipAdamW (what ``training.adamw`` / ``configure_optimizers`` return on the GPU): gradient-norm clip + AdamW
+    in three HIP launches against torch's clip_grad_norm_ + AdamW (single-tensor implementation) over several steps --
+    clip active and inactive, element counts that are not multiples of 4 or of the chunk, a parameter that is a view at
+    an address that is not 16-byte aligned, a parameter that never receives a gradient, two parameter groups with
+    different lr / weight decay, a parameter that starts receiving gradients two steps late (its own step count), and
+    the optimizer state moving to a plain torch.optim.AdamW through state_dict."""
+    from e3diff_amd.optim import ClipAdamW
+    from e3diff_amd.training import adamw, clip_and_step
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    flat = torch.randn(4 * 8192 + 7, device=dev)
+    shapes = [(257, 33), (1000,), (3,), (8192 * 3 + 5,), (64, 768)]
+    base = [torch.randn(*s, device=dev) for s in shapes]
+    idle0 = torch.randn(5, 5, device=dev)
+    assert isinstance(adamw([torch.nn.Parameter(base[0].clone())], lr=1e-3, weight_decay=0.1), ClipAdamW)
+    for scale in (50.0, 1e-3):
+        models = []
+        for impl in ("torch", "hip"):
+            ps = [torch.nn.Parameter(b.clone()) for b in base]
+            odd = torch.nn.Parameter(flat.clone()[1:1 + 8192 + 2])            # data_ptr % 16 == 4
+            idle = torch.nn.Parameter(idle0.clone())                          # never gets a gradient
+            late = torch.nn.Parameter(base[1].clone())                        # first gradient at step 2
+            groups = [dict(params=ps[:3] + [odd, idle], lr=1e-2, weight_decay=0.1), dict(params=ps[3:] + [late], lr=3e-3, weight_decay=0.0)]
+            opt = torch.optim.AdamW(groups, foreach=False) if impl == "torch" else ClipAdamW(groups)
+            norms = []
+            for step in range(5):
+                g = torch.Generator(device=dev).manual_seed(100 + step)
+                for p in ps + [odd] + ([late] if step >= 2 else []):
+                    p.grad = torch.randn(p.shape, device=dev, generator=g) * scale
+                params = [p for gr in opt.param_groups for p in gr["params"]]
+                if impl == "torch":
+                    norms.append(torch.nn.utils.clip_grad_norm_(params, 1.0))
+                    opt.step()
+                else:
+                    norms.append(clip_and_step(params, opt, 1.0).clone())
+                opt.zero_grad(set_to_none=True)
+            models.append((ps + [odd, late, idle], norms, opt))
+        (pa, na, oa), (pb, nb, ob) = models
+        for x, y in zip(na, nb):
+            assert abs(float(x) - float(y)) <= 2e-6 * float(x)
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), (x - y).abs().max()
+        assert torch.equal(pa[-1], pb[-1])                                    # the idle parameter did not move
+        # state round trip: ClipAdamW's state drives a plain torch AdamW to the same next step
+        sd = ob.state_dict()
+        assert {int(v["step"]) for v in sd["state"].values()} == {5, 3}
+        oc = torch.optim.AdamW([dict(params=g_["params"]) for g_ in ob.param_groups], foreach=False)
+        oc.load_state_dict(sd)
+        for opt, ps in ((oa, pa), (oc, pb)):
+            for i, p in enumerate(ps[:-1]):
+                p.grad = torch.full_like(p, 0.01 * (i + 1))
+            opt.step()
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7)
