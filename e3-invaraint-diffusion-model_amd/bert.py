@@ -8,6 +8,8 @@ execute the math as fused gfx950 kernels on [B*L, H] row-major activations.
 """
 from dataclasses import dataclass
 
+import os
+
 import torch
 from torch import nn
 
@@ -116,33 +118,85 @@ class BertEncoder(nn.Module):
 
 
 # ----------------------------------------------------------------------------- packed weights
-def _packed(owner, name, tensors):
-    """cat() of per-projection weights.  Inference: cached on the owner and rebuilt when any
-    source parameter changes (in-place update or re-assignment).  Training (a source requires grad
-    and autograd is on): a fresh differentiable torch.cat, so the packed gradient is split back
-    onto query/key/value by autograd."""
-    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        out = torch.cat(list(tensors), dim=0)
-        out._e3d_parts = list(tensors)    # autograd.deferred_weight_grads writes the row blocks' gradients straight
-        return out                        # into these parameters instead of through cat's backward
-    key = ops.weight_key(*tensors)    # includes the optimizer-step generation: fused optimizers do not bump _version
-    cache = owner.__dict__.setdefault("_e3d_pack", {})
-    hit = cache.get(name)
-    if hit is None or hit[0] != key:
+TIE_PACKED = os.environ.get("E3D_TIE_QKV", "1") == "1"     # 0: a fresh torch.cat per forward (A/B runs)
+
+
+class _TiedPack(torch.autograd.Function):
+    """(packed weight, packed bias) as differentiable functions of the parameters whose storage they ALIAS (``_tie``): no
+    copy and no kernel in either direction.  The backward (only reached when the weight gradients are not deferred:
+    autograd.deferred_weight_grads writes the row blocks' gradients straight into the parameters) hands each parameter
+    its row block of the packed gradient."""
+
+    @staticmethod
+    def forward(ctx, w_packed, b_packed, n, *parts):
+        ctx.n, ctx.rows = n, [p.shape[0] for p in parts[:n]]
+        return w_packed.view(w_packed.shape), b_packed.view(b_packed.shape)
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        gws = gw.split(ctx.rows, 0) if gw is not None else (None,) * ctx.n
+        gbs = gb.split(ctx.rows, 0) if gb is not None else (None,) * ctx.n
+        return (None, None, None) + tuple(gws) + tuple(gbs)
+
+
+def _tie(owner, name, tensors):
+    """One buffer [sum rows, ...] whose row blocks ARE the given parameters: on first use (and whenever a parameter has
+    moved: ``module.to()``, a re-assigned ``.data``) the values are packed once and every parameter's ``.data`` becomes a
+    view of its block.  In-place updates (optimizers, ``load_state_dict``, broadcasts) then keep the packed tensor current
+    for free; names, shapes and ``state_dict`` are unchanged."""
+    tied = owner.__dict__.setdefault("_e3d_tied", {})
+    ent = tied.get(name)
+    ok = ent is not None and ent.device == tensors[0].device
+    if ok:
+        at = ent.data_ptr()
+        for t in tensors:
+            if t.data_ptr() != at or not t.is_contiguous():
+                ok = False
+                break
+            at += 4 * t.numel()
+    if not ok:
         with torch.no_grad():
-            hit = (key, torch.cat([t.detach() for t in tensors], dim=0).contiguous())
-        cache[name] = hit
-    return hit[1]
+            ent = torch.cat([t.detach() for t in tensors], dim=0).contiguous()
+            r0 = 0
+            for t in tensors:
+                t.data = ent[r0:r0 + t.shape[0]]
+                r0 += t.shape[0]
+        tied[name] = ent
+    return ent
+
+
+def _packed(owner, name, weights, biases):
+    """(cat(weights), cat(biases)) of per-projection parameters.  Inference: copies cached on the owner and rebuilt when
+    any source parameter changes (in-place update or re-assignment).  Training (a source requires grad and autograd is
+    on): the parameters are tied to packed buffers (``_tie``) and the pair is a zero-copy alias of them -- a training
+    step used to spend 72 cat kernels (0.5 ms) re-packing weights the optimizer had just updated."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in weights):
+        if TIE_PACKED and all(t.dtype == torch.float32 for t in list(weights) + list(biases)):
+            w, b = _TiedPack.apply(_tie(owner, "w_" + name, weights), _tie(owner, "b_" + name, biases), len(weights),
+                                   *weights, *biases)
+        else:
+            w, b = torch.cat(list(weights), dim=0), torch.cat(list(biases), dim=0)
+        w._e3d_parts, b._e3d_parts = list(weights), list(biases)   # autograd.deferred_weight_grads writes the row blocks'
+        return w, b                                                 # gradients straight into these parameters
+    out = []
+    cache = owner.__dict__.setdefault("_e3d_pack", {})
+    for key_name, tensors in (("w_" + name, weights), ("b_" + name, biases)):
+        key = ops.weight_key(*tensors)    # includes the optimizer-step generation: fused optimizers do not bump _version
+        hit = cache.get(key_name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, torch.cat([t.detach() for t in tensors], dim=0).contiguous())
+            cache[key_name] = hit
+        out.append(hit[1])
+    return out[0], out[1]
 
 
 def qkv_weights(sa):
-    return (_packed(sa, "w_qkv", [sa.query.weight, sa.key.weight, sa.value.weight]),
-            _packed(sa, "b_qkv", [sa.query.bias, sa.key.bias, sa.value.bias]))
+    return _packed(sa, "qkv", [sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias])
 
 
 def kv_weights(sa):
-    return (_packed(sa, "w_kv", [sa.key.weight, sa.value.weight]),
-            _packed(sa, "b_kv", [sa.key.bias, sa.value.bias]))
+    return _packed(sa, "kv", [sa.key.weight, sa.value.weight], [sa.key.bias, sa.value.bias])
 
 
 def dropout_rates(module):

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     int P, const float* __restrict__ key_mask, const float* __restrict__ dout, const float* __restrict__ outp,
     const float* __restrict__ lse, float* __restrict__ dq, int64_t dq_bs, int64_t dq_rs, float* __restrict__ dk,
     int64_t dk_bs, int64_t dk_rs, float* __restrict__ dv, int64_t dv_bs, int64_t dv_rs, float* __restrict__ dE_part, int nh,
-    int Lq, int Lk, E3dDrop drop) {
+    int Lq, int Lk, E3dDrop drop_in) {
+    const E3dDrop drop = e3d_drop_resolve(drop_in);   // + the device-side epoch (graph replays: e3d_common.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* img0 = smem_raw;               // phase A: Q      phase B: K
     unsigned char* img1 = smem_raw + IMG_B;       // phase A: dO     phase B: V

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_split_kernel(
     const float* __restrict__ key_mask, const float* __restrict__ dout, const float* __restrict__ outp,
     const float* __restrict__ lse, float* __restrict__ dq, int64_t dq_bs, int64_t dq_rs, float* __restrict__ Pm,
     float* __restrict__ dSm, float* __restrict__ dE_part, int nh, int Lq, int Lk, int q_tiles, int n_units,
-    E3dDrop drop) {
+    E3dDrop drop_in) {
+    const E3dDrop drop = e3d_drop_resolve(drop_in);   // + the device-side epoch (graph replays: e3d_common.h)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qi = lane & 31, half = lane >> 5;

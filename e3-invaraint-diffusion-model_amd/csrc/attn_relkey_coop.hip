@@ -169,7 +169,8 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const typename AV<E>::x8* __restrict__ e_frag,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq, int Lk,
-    int groups_per_bh, int skip_padded_tiles, E3dBounds bnd, float rescale_tau, E3dDrop drop) {
+    int groups_per_bh, int skip_padded_tiles, E3dBounds bnd, float rescale_tau, E3dDrop drop_in) {
+    const E3dDrop drop = e3d_drop_resolve(drop_in);   // + the device-side epoch (graph replays: e3d_common.h)
     typedef typename AV<E>::x8 bf16x8;   // (names kept from the bf16 form: 8 / 4 split terms of type E)
     typedef typename AV<E>::x4 bf16x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split_kernel(
     const float* __restrict__ q, int64_t q_bs, int64_t q_rs, const float* __restrict__ k, int64_t k_bs,
     int64_t k_rs, const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const float* __restrict__ dist_emb,
     int P, const float* __restrict__ key_mask, float* __restrict__ out, float* __restrict__ lse, int nh, int Lq,
-    int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dBounds bnd, E3dDrop drop) {
+    int Lk, int q_tiles, int n_units, int skip_padded_tiles, E3dBounds bnd, E3dDrop drop_in) {
+    const E3dDrop drop = e3d_drop_resolve(drop_in);   // + the device-side epoch (graph replays: e3d_common.h)
     typedef typename AV<E>::x8 bf16x8;   // (name kept from the bf16 form: 8 split terms of type E)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

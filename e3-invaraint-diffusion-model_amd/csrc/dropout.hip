@@ -6,8 +6,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, E3dDrop d, float* __restrict__ out,
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, E3dDrop d_in, float* __restrict__ out,
                                                       int64_t n) {
+    const E3dDrop d = e3d_drop_resolve(d_in);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4 + 1; i += stride) {
         float m[4];
@@ -24,8 +25,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 }
 
 // multipliers of the attention-probability dropout, [B*nh, Lq, Lk] (test aid: the kernels never store them)
-__global__ __launch_bounds__(256) void attn_drop_mask_kernel(E3dDrop d, float* __restrict__ out, int Lq, int Lk,
+__global__ __launch_bounds__(256) void attn_drop_mask_kernel(E3dDrop d_in, float* __restrict__ out, int Lq, int Lk,
                                                              int64_t n_rows) {
+    const E3dDrop d = e3d_drop_resolve(d_in);
     const int64_t row = blockIdx.x;   // (bh, q)
     if (row >= n_rows) return;
     const int bh = (int)(row / Lq), q = (int)(row % Lq);

@@ -167,14 +167,25 @@ struct E3dDrop {
     uint64_t seed;
     uint32_t thr;
     float scale;
+    const uint64_t* epoch;   // device word added to the seed inside the kernel (may be null): see e3d_dropout_set_epoch_ptr
 };
+// The word registered for the calling thread's current device (capi.hip), or null.  A captured HIP graph bakes the
+// ``seed`` argument of every dropout launch; a training step replayed from a graph advances this word instead, so every
+// replay draws fresh decisions while forward and backward of one step still agree.
+const uint64_t* e3d_dropout_epoch_ptr();
 static inline E3dDrop e3d_drop_make(float p, uint64_t seed) {
     E3dDrop d;
     long t = lrintf(p * 65536.0f);
     t = t < 0 ? 0 : (t > 65535 ? 65535 : t);
     d.seed = seed;
+    d.epoch = e3d_dropout_epoch_ptr();
     d.thr = (uint32_t)t;
     d.scale = 65536.0f / (float)(65536 - t);
+    return d;
+}
+__device__ __forceinline__ E3dDrop e3d_drop_resolve(E3dDrop d) {   // once, at kernel entry
+    if (d.epoch) d.seed += *d.epoch * 0xD1342543DE82EF95ull;
+    d.epoch = nullptr;
     return d;
 }
 __device__ __forceinline__ void e3d_drop_mult4(const E3dDrop d, uint64_t idx4, float (&m)[4]) {

@@ -89,7 +89,13 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* const* __restrict__ pa
                                                    float* const* __restrict__ exp_avg, float* const* __restrict__ exp_avg_sq,
                                                    const int64_t* __restrict__ numel, const int* __restrict__ chunk_tensor,
                                                    const int64_t* __restrict__ chunk_first, const float* __restrict__ clip,
-                                                   AdamScalars a) {
+                                                   AdamScalars a, const float* __restrict__ dyn) {
+    if (dyn) {   // learning rate and step count from device memory (a captured graph cannot carry them as arguments)
+        a.lr = dyn[0];
+        const double step = (double)dyn[1] + 1.0;
+        a.bc1 = (float)(1.0 - pow((double)a.beta1, step));
+        a.bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, step));
+    }
     const int t = chunk_tensor[blockIdx.x];
     const int64_t first = chunk_first[blockIdx.x];
     float* p = params[t] + first;
@@ -144,6 +150,20 @@ extern "C" int e3d_adamw_step(float* const* params, const float* const* grads, f
     a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, numel,
-                       chunk_tensor, chunk_first, norm_and_clip, a);
+                       chunk_tensor, chunk_first, norm_and_clip, a, (const float*)nullptr);
     return e3d_launch_status("e3d_adamw_step");
+}
+
+extern "C" int e3d_adamw_step_dyn(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                  const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first, int n_chunks,
+                                  const float* norm_and_clip, const float* lr_and_step, float beta1, float beta2, float eps,
+                                  float weight_decay, void* stream) {
+    E3D_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && chunk_tensor && chunk_first && lr_and_step,
+                "adamw_step_dyn: null pointer");
+    E3D_REQUIRE(n_chunks > 0, "adamw_step_dyn: no chunks");
+    AdamScalars a;
+    a.lr = 0.f; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, numel,
+                       chunk_tensor, chunk_first, norm_and_clip, a, lr_and_step);
+    return e3d_launch_status("e3d_adamw_step_dyn");
 }

@@ -7,6 +7,7 @@ through ``ligand_feature_emb`` (``receptor_feature_emb`` is dead weight that sti
 checkpoint); the timestep embedding is ADDED to both angle embeddings and also drives the final
 ``decoder_normalize`` block; training feeds t/T, sampling feeds the raw integer step.
 """
+import os
 from typing import List
 
 import torch
@@ -20,6 +21,14 @@ from ..training import adamw
 from .utils import BlosumTransition, PredefinedNoiseScheduleDiscrete, elbo_loss
 
 AA_VOCAB = "ACDEFGHIKLMNPQRSTVWY"
+MASKED_LOSS = os.environ.get("E3D_MASKED_LOSS", "1") == "1"   # 0: the reference's boolean-mask indexing (host syncs per step)
+
+
+def _is_plain_cross_entropy(fn):
+    """nn.CrossEntropyLoss() as the reference's train script builds it (sequence_model/train_model.py): mean reduction, no
+    class weights, no label smoothing -- the form ``get_loss`` can take as a masked mean."""
+    return (type(fn) is nn.CrossEntropyLoss and fn.weight is None and fn.reduction == "mean" and fn.ignore_index == -100
+            and float(getattr(fn, "label_smoothing", 0.0)) == 0.0)
 
 
 class ConditionalBertForDiffusionBase(nn.Module):
@@ -122,10 +131,32 @@ class PeptideDiff(ConditionalBertForDiffusionBase):
         pred_aa = self.forward(t_norm, noised_ligand_seq, batch["ligand_angles"], batch["ligand_attn_mask"],
                                batch["receptor_seq"], batch["receptor_angles"], batch["receptor_attn_mask"])
         n_lig = ligand_mask.sum()
+        kept = ligand_mask & (~noised_mask)
+        if MASKED_LOSS and _is_plain_cross_entropy(self.loss_function):
+            # The same six numbers without boolean-mask indexing (whose data-dependent result sizes cost a device-to-host
+            # synchronisation each, in the middle of every training step): means over the noised / kept positions as
+            # masked sums divided by counts.  An empty selection gives 0 / 0 = NaN, as the indexed means do.
+            zero = torch.zeros((), dtype=pred_aa.dtype, device=pred_aa.device)
+
+            def masked_mean(values, mask):
+                return torch.where(mask, values, zero).sum() / mask.sum()
+
+            aa_noise_rate = ((noised_idx == true_idx) & ligand_mask).sum() / n_lig
+            aa_recovery_rate = ((pred_aa.argmax(dim=-1) == true_idx) & ligand_mask).sum() / n_lig
+            nll = -F.log_softmax(pred_aa, dim=-1).gather(-1, true_idx.unsqueeze(-1)).squeeze(-1)      # CE per position
+            aa_noised_loss = masked_mean(nll, noised_mask)
+            aa_all_loss = masked_mean(nll, kept)
+            # elbo_loss(pred[noised], onehot[noised]) (utils.py): mean row entropy + KL "batchmean" = sums over the rows / rows
+            p_model = F.softmax(pred_aa, dim=-1)
+            logp_model = F.log_softmax(pred_aa + 1e-6, dim=-1)
+            p_target = F.softmax(batch["ligand_seq"], dim=-1)
+            kl_rows = (p_target * (p_target.log() - logp_model)).sum(dim=-1)
+            entropy_rows = -(p_model * logp_model).sum(dim=-1)
+            elbo = masked_mean(entropy_rows, noised_mask) + masked_mean(kl_rows, noised_mask)
+            return aa_noised_loss + elbo, elbo, aa_noised_loss, aa_all_loss, aa_recovery_rate, aa_noise_rate
         aa_noise_rate = (noised_idx[ligand_mask] == true_idx[ligand_mask]).sum() / n_lig
         aa_recovery_rate = (pred_aa.argmax(dim=-1)[ligand_mask] == true_idx[ligand_mask]).sum() / n_lig
         aa_noised_loss = self.loss_function(pred_aa[noised_mask].view(-1, 20), true_idx[noised_mask].view(-1))
-        kept = ligand_mask & (~noised_mask)
         aa_all_loss = self.loss_function(pred_aa[kept].view(-1, 20), true_idx[kept].view(-1))
         elbo = elbo_loss(pred_aa[noised_mask], batch["ligand_seq"][noised_mask])
         return aa_noised_loss + elbo, elbo, aa_noised_loss, aa_all_loss, aa_recovery_rate, aa_noise_rate

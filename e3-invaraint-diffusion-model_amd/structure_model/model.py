@@ -13,7 +13,11 @@ from .. import bert, ops
 from ..blocks import (BertEmbeddings, GaussianFourierProjection, Predictor, SELayer, flat2d,
                       require_gpu)
 from ..training import adamw
-from .utils import radian_l1_loss, radian_smooth_l1_loss
+import os
+
+from .utils import elementwise_form, radian_l1_loss, radian_smooth_l1_loss
+
+MASKED_LOSS = os.environ.get("E3D_MASKED_LOSS", "1") == "1"   # 0: the reference's indexed form (a host sync per step)
 
 
 class ReceptorCache:
@@ -121,11 +125,32 @@ class ConditionalBertForDiffusion(ConditionalBertForDiffusionBase):
         return self.loss_terms_from_prediction(predicted_noise, known_noise, batch["ligand_attn_mask"])
 
     def loss_terms_from_prediction(self, predicted_noise, known_noise, ligand_attn_mask):
+        """``fn(pred[rows, cols, i], noise[rows, cols, i])`` per feature over ``rows, cols = torch.where(mask)``
+        (reference model.py:290-303).  For this package's own loss functions the mean over the selected positions is
+        taken as a masked sum / count: the same value without the index lists, whose data-dependent length costs a
+        device-to-host synchronisation in the middle of every training step (the GPU drains before the backward pass can
+        be enqueued, and the step cannot be captured in a graph).  Unknown callables take the indexed path."""
+        n_feat = known_noise.shape[-1]
+        fns = [self.loss_func[i] if isinstance(self.loss_func, list) else self.loss_func for i in range(n_feat)]
+        elems = [elementwise_form(fn) for fn in fns]
+        if all(e is not None for e in elems) and MASKED_LOSS:
+            sel = (ligand_attn_mask != 0).unsqueeze(-1)                       # [B, L, 1]
+            count = sel.sum().to(predicted_noise.dtype)
+            groups = {}                                                       # features sharing a function: one pass
+            for i, fn in enumerate(fns):
+                key = (fn.func, tuple(sorted(fn.keywords.items()))) if isinstance(fn, functools.partial) else (fn, ())
+                groups.setdefault(key, []).append(i)
+            terms = [None] * n_feat
+            for idx in groups.values():
+                e = elems[idx[0]](predicted_noise[..., idx], known_noise[..., idx])          # [B, L, len(idx)]
+                sums = torch.where(sel, e, torch.zeros((), dtype=e.dtype, device=e.device)).sum(dim=(0, 1)) / count
+                for j, i in enumerate(idx):
+                    terms[i] = sums[j]
+            return torch.stack(terms)
         rows, cols = torch.where(ligand_attn_mask)
         terms = []
-        for i in range(known_noise.shape[-1]):
-            fn = self.loss_func[i] if isinstance(self.loss_func, list) else self.loss_func
-            terms.append(fn(predicted_noise[rows, cols, i], known_noise[rows, cols, i]))
+        for i in range(n_feat):
+            terms.append(fns[i](predicted_noise[rows, cols, i], known_noise[rows, cols, i]))
         return torch.stack(terms)
 
     def training_step(self, batch, batch_idx=0):

@@ -75,29 +75,50 @@ def _wrapped_delta(prediction, truth):
     return modulo_with_wrapped_range(truth - prediction, -torch.pi, torch.pi)
 
 
+def _radian_l1_elem(input, target):
+    delta = (target % TWO_PI) - (input % TWO_PI)
+    delta = (delta + torch.pi) % TWO_PI - torch.pi
+    return delta.abs()
+
+
 def radian_l1_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """Mean absolute angular difference (reference utils.py:61-76); both arguments are first
     reduced mod 2*pi, exactly as the reference does."""
-    delta = (target % TWO_PI) - (input % TWO_PI)
-    delta = (delta + torch.pi) % TWO_PI - torch.pi
-    return delta.abs().mean()
+    return _radian_l1_elem(input, target).mean()
 
 
 def radian_smooth_l1_loss(input: torch.Tensor, target: torch.Tensor, beta: float = 1.0,
                           circle_penalty: float = 0.0) -> torch.Tensor:
     """Huber-style loss on the wrapped difference (reference utils.py:78-109): quadratic inside
     ``beta``, linear outside; ``circle_penalty`` charges whole turns of ``input``."""
+    return _radian_smooth_l1_elem(input, target, beta, circle_penalty).mean()
+
+
+def _radian_smooth_l1_elem(input, target, beta=1.0, circle_penalty=0.0):
     if target.shape != input.shape:
         raise AssertionError(f"Mismatched shapes: {input.shape} != {target.shape}")
     if not beta > 0:
         raise AssertionError("beta must be positive")
     delta = _wrapped_delta(input, target)
     mag = delta.abs()
-    loss = torch.where(mag < beta, 0.5 * (delta ** 2) / beta, mag - 0.5 * beta).mean()
+    loss = torch.where(mag < beta, 0.5 * (delta ** 2) / beta, mag - 0.5 * beta)
     if circle_penalty > 0:
-        turns = torch.div(input.abs(), torch.pi, rounding_mode="trunc")
-        loss = loss + circle_penalty * turns.mean()
+        loss = loss + circle_penalty * torch.div(input.abs(), torch.pi, rounding_mode="trunc")
     return loss
+
+
+def elementwise_form(fn):
+    """The per-element form ``e`` of one of this module's loss functions (``fn(x, y) == e(x, y).mean()``), or None for a
+    callable this module does not know: lets the training step take the mean over the un-padded positions as a masked
+    sum -- no ``torch.where(mask)`` index lists, hence no device-to-host synchronisation inside the step."""
+    import functools
+    if fn is radian_l1_loss:
+        return _radian_l1_elem
+    if fn is radian_smooth_l1_loss:
+        return _radian_smooth_l1_elem
+    if isinstance(fn, functools.partial) and fn.func is radian_smooth_l1_loss and not fn.args:
+        return functools.partial(_radian_smooth_l1_elem, **fn.keywords)
+    return None
 
 
 def tolerant_comparison_check(values, cmp, v):

@@ -369,3 +369,82 @@ def test_clip_adamw_on_cpu_parameters_is_torch_adamw(pkg):
     assert outs[0][1] == outs[1][1]
     assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
     assert outs[0][2]["param_groups"][0].keys() == outs[1][2]["param_groups"][0].keys()
+
+
+def test_training_packs_qkv_by_tying_parameter_storage(pkg):
+    """bert.qkv_weights in training mode: query / key / value parameters become row blocks of ONE buffer (no cat per
+    step); the packed pair aliases it, follows in-place updates for free, routes gradients to the parameters when the
+    weight gradients are not deferred, survives a parameter being moved, and leaves names / shapes / state_dict alone."""
+    from e3diff_amd import bert
+    torch.manual_seed(0)
+    att = bert.BertSelfAttention(bert.BertConfig(hidden_size=128, num_attention_heads=2, max_position_embeddings=8))
+    want = torch.cat([att.query.weight, att.key.weight, att.value.weight]).detach().clone()
+    keys0 = list(att.state_dict().keys())
+    w, b = bert.qkv_weights(att)
+    assert torch.equal(w.detach(), want) and w.requires_grad and b.requires_grad
+    assert w.data_ptr() == att.query.weight.data_ptr() and att.value.weight.data_ptr() == w.data_ptr() + 4 * 2 * 128 * 128
+    assert w._e3d_parts[1] is att.key.weight and list(att.state_dict().keys()) == keys0
+    assert att.key.weight.shape == (128, 128) and att.key.weight.is_contiguous() and att.key.weight.is_leaf
+    (2 * w.sum() + 3 * b.sum()).backward()
+    assert torch.equal(att.key.weight.grad, torch.full((128, 128), 2.0)) and torch.equal(att.value.bias.grad, torch.full((128,), 3.0))
+    opt = torch.optim.SGD(att.parameters(), lr=0.5)
+    opt.step()                                                    # in place: the packed buffer follows without a copy
+    w2, _ = bert.qkv_weights(att)
+    assert w2.data_ptr() == w.data_ptr() and torch.equal(w2.detach(), want - 1.0)
+    att.key.weight.data = att.key.weight.data.clone() + 5.0       # a parameter moved: re-tied, values kept
+    w3, _ = bert.qkv_weights(att)
+    assert torch.equal(w3.detach()[128:256], want[128:256] - 1.0 + 5.0) and att.key.weight.data_ptr() == w3.data_ptr() + 4 * 128 * 128
+    with torch.no_grad():                                         # the inference cache sees the same values
+        assert torch.equal(bert.qkv_weights(att)[0], w3.detach())
+    sd = att.state_dict()
+    att2 = bert.BertSelfAttention(bert.BertConfig(hidden_size=128, num_attention_heads=2, max_position_embeddings=8))
+    att2.load_state_dict(sd, strict=True)
+    assert torch.equal(att2.value.weight, att.value.weight)
+
+
+def test_training_losses_without_index_lists_equal_the_indexed_forms(pkg):
+    """The training steps take their means over the un-padded / noised positions as masked sums (no ``torch.where(mask)``
+    or boolean-mask indexing: those cost a device-to-host synchronisation per step): same values and same gradients as the
+    reference's indexed forms (structure_model/model.py:290-303, sequence_model/model.py:313-345), in fp64 on the CPU."""
+    from e3diff_amd.sequence_model import model as SQ
+    from e3diff_amd.structure_model import model as ST
+    torch.manual_seed(0)
+    B, L = 6, 16
+    mask = torch.arange(L)[None] < torch.tensor([3, 16, 1, 9, 12, 5])[:, None]
+
+    class S:
+        loss_func = [ST.ConditionalBertForDiffusion.diheral_loss_func] * 4 + [ST.ConditionalBertForDiffusion.angle_loss_func] * 4
+    pred = (torch.randn(B, L, 8, dtype=torch.float64) * 3).requires_grad_(True)
+    noise = torch.randn(B, L, 8, dtype=torch.float64) * 3
+    outs = []
+    for masked in (True, False):
+        ST.MASKED_LOSS = masked
+        t = ST.ConditionalBertForDiffusion.loss_terms_from_prediction(S(), pred, noise, mask.float())
+        outs.append((t, torch.autograd.grad(t.mean(), pred)[0]))
+    ST.MASKED_LOSS = True
+    assert (outs[0][0] - outs[1][0]).abs().max() < 1e-14 and (outs[0][1] - outs[1][1]).abs().max() < 1e-14
+    # a loss callable this package does not know keeps the indexed path
+    S.loss_func = [lambda a, b: (a - b).abs().mean()] * 8
+    t = ST.ConditionalBertForDiffusion.loss_terms_from_prediction(S(), pred, noise, mask.float())
+    assert torch.allclose(t[0], (pred - noise).abs()[..., 0][mask].mean())
+
+    class Q:
+        loss_function = torch.nn.CrossEntropyLoss()
+
+        def forward(self, *a):
+            return logits
+    true = torch.randint(0, 20, (B, L))
+    seq = torch.nn.functional.one_hot(true, 20).double() * mask[..., None]
+    noised_idx = torch.where(torch.rand(B, L) < 0.5, torch.randint(0, 20, (B, L)), true)
+    noised = torch.nn.functional.one_hot(noised_idx, 20).double() * mask[..., None]
+    logits = torch.randn(B, L, 20, dtype=torch.float64, requires_grad=True)
+    batch = dict(ligand_attn_mask=mask.float(), ligand_seq=seq, ligand_angles=None, receptor_seq=None, receptor_angles=None,
+                 receptor_attn_mask=None)
+    outs = []
+    for masked in (True, False):
+        SQ.MASKED_LOSS = masked
+        six = SQ.PeptideDiff.get_loss(Q(), batch, None, noised)
+        outs.append((torch.stack([x.double() for x in six]).detach(), torch.autograd.grad(six[0], logits)[0]))
+    SQ.MASKED_LOSS = True
+    assert (outs[0][0] - outs[1][0]).abs().max() < 1e-14 and (outs[0][1] - outs[1][1]).abs().max() < 1e-14
+    assert not SQ._is_plain_cross_entropy(torch.nn.CrossEntropyLoss(label_smoothing=0.1))

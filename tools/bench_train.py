@@ -88,6 +88,14 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         torch.cuda.synchronize()
         if ddp and dist.is_initialized():
             dist.barrier()
+        # host side alone: the time Python needs to ENQUEUE one step into an empty queue (the step is host-bound when this
+        # approaches ms_per_step)
+        h0 = time.perf_counter()
+        step()
+        host_ms = (time.perf_counter() - h0) * 1e3
+        torch.cuda.synchronize()
+        if ddp and dist.is_initialized():
+            dist.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
@@ -106,7 +114,7 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         dist.all_gather(ws, w)
         assert all(float(t) == float(ws[0]) for t in ws), "ranks diverged"
     return {"model": model_name, "batch": B, "seq_len": L, "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
-            "arithmetic": mode, "dropout": dropout, "ms_per_step": dt * 1e3, "samples_per_s": B / dt,
+            "arithmetic": mode, "dropout": dropout, "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "host_enqueue_ms": host_ms,
             **({"ranks": dist.get_world_size(), "global_batch": B * dist.get_world_size(),
                 "global_samples_per_s": B * dist.get_world_size() / dt, "backend": dist.get_backend(),
                 "gradient_MB_per_step": sum(p.numel() for p in params) * 4 / 1e6,
@@ -126,7 +134,7 @@ def main():
     r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout, arithmetic=args.arithmetic)
     print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} layers={r['layers']} params={r['params_M']:.1f}M "
           f"gemm_mode={r['arithmetic']} dropout={r['dropout']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
-          f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB)", flush=True)
+          f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB; host enqueue {r['host_enqueue_ms']:.1f} ms)", flush=True)
 
 
 if __name__ == "__main__":
