@@ -6,7 +6,7 @@ the C-ABI of include/e3d_hip.h (csrc/, loaded by hip.py).  No CPU fallback.
 """
 from . import hip  # noqa: F401
 
-__all__ = ["hip", "ops", "bert", "blocks", "training", "sharding", "autograd", "biolip", "structure_model", "sequence_model"]
+__all__ = ["hip", "ops", "bert", "blocks", "training", "optim", "sharding", "autograd", "biolip", "structure_model", "sequence_model"]
 
 
 def __getattr__(name):

@@ -325,6 +325,25 @@ def set_attn_mode(mode):
     return prev
 
 
+_DROPOUT_EPOCH = {}
+
+
+def dropout_epoch(device):
+    """The device word every dropout launch on ``device`` adds to its seed INSIDE the kernel (created and registered with
+    the library on first use: include/e3d_hip.h, e3d_dropout_set_epoch_ptr).  A training step replayed from a HIP graph
+    carries the seeds of its capture as baked arguments; it advances this word instead (``training.GraphedStep``), so every
+    replay draws fresh decisions while the forward and backward launches of one step still agree."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _DROPOUT_EPOCH.get(idx)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=f"cuda:{idx}")
+        with torch.cuda.device(idx):
+            hip.check(hip.lib().e3d_dropout_set_epoch_ptr(t.data_ptr()), "e3d_dropout_set_epoch_ptr")
+        _DROPOUT_EPOCH[idx] = t
+    return t
+
+
 def next_dropout_seed():
     """A fresh 63-bit seed for one dropout site call, drawn from torch's global CPU generator
     (so ``torch.manual_seed`` makes training runs repeatable)."""

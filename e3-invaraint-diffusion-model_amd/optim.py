@@ -19,6 +19,7 @@ class ClipAdamW(torch.optim.AdamW):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._e3d_clip = None        # max_norm of the NEXT step (step_clipped sets it; None: no clip)
+        self.device_scalars = False  # learning rate and step counts read from device memory (graph replay): use_device_scalars
         self._e3d_tab = None         # device tables of the current parameter partition
         self.last_norm = None        # total gradient norm of the last clipped step (0-dim device tensor)
 
@@ -31,6 +32,35 @@ class ClipAdamW(torch.optim.AdamW):
         finally:
             self._e3d_clip = None
         return self.last_norm
+
+    def use_device_scalars(self, on=True):
+        """Keep the learning rate and the step count of every parameter range in device memory (``e3d_adamw_step_dyn``)
+        so that a captured HIP graph of the step can be replayed: ``sync_lr()`` before a replay pushes a changed learning
+        rate, ``note_replayed_step()`` after it does the host-side bookkeeping ``step()`` would have done."""
+        if bool(on) != self.device_scalars:
+            self.device_scalars = bool(on)
+            self._e3d_tab = None
+
+    def sync_lr(self):
+        tab = self._e3d_tab
+        if tab is None or "dyn" not in tab:
+            return
+        for r, (gi, _, _) in enumerate(tab["dyn_ranges"]):
+            lr = float(self.param_groups[gi]["lr"])
+            if tab["dyn_lr"][r] != lr:
+                tab["dyn_lr"][r] = lr
+                tab["dyn"][r, 0:1].fill_(lr)
+
+    def note_replayed_step(self, delta=1):
+        """Host-side bookkeeping of one replayed step (``delta=-1``: undo that of a capture pass, which runs ``step()`` on
+        the host without executing anything on the device)."""
+        tab = self._e3d_tab
+        if tab is None:
+            return
+        tab["ranges"] = [[(c0, c1, step + delta) for (c0, c1, step) in rs] for rs in tab["ranges"]]
+        torch._foreach_add_(tab["step_tensors"], delta)
+        tab["gptr_host"] = None      # the graph re-copies ITS gradient pointers: an eager step must upload its own again
+        self._opt_called = True      # what LR schedulers look at to order scheduler.step() after optimizer.step()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -74,10 +104,17 @@ class ClipAdamW(torch.optim.AdamW):
         dev = tab["device"]
         stream = torch.cuda.current_stream(dev).cuda_stream
         # gradient pointers: new tensors every step (zero_grad(set_to_none=True)), normally at last step's addresses
+        capturing = torch.cuda.is_current_stream_capturing()
         gptr = [p.grad.data_ptr() for _, ps in parts for p in ps]
         if gptr != tab["gptr_host"]:
             tab["gptr_host"] = gptr
-            tab["gptr"] = torch.tensor(gptr, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+            if capturing:      # a persistent staging buffer (no host allocation while a stream is capturing; replays re-copy it)
+                tab["gptr_pin"].copy_(torch.tensor(gptr, dtype=torch.int64))
+                tab["gptr"].copy_(tab["gptr_pin"], non_blocking=True)
+            else:              # eager: a fresh pinned tensor per change (an earlier asynchronous copy may still be reading the last one)
+                tab["gptr"].copy_(torch.tensor(gptr, dtype=torch.int64).pin_memory(), non_blocking=True)
+        if self.device_scalars and not capturing:
+            self.sync_lr()
         nc = None
         if self._e3d_clip is not None:
             nc = tab["norm_and_clip"]
@@ -85,17 +122,28 @@ class ClipAdamW(torch.optim.AdamW):
                                                tab["chunk_first"].data_ptr(), tab["n_chunks"], self._e3d_clip,
                                                tab["partial"].data_ptr(), nc.data_ptr(), stream), "e3d_grad_global_norm")
             self.last_norm = nc[0]
+        r = -1
         for k, (gi, ps) in enumerate(parts):
             group = self.param_groups[gi]
             for (c0, c1, step) in tab["ranges"][k]:
                 b1, b2 = group["betas"]
                 lr = group["lr"]
+                r += 1
+                if self.device_scalars:
+                    hip.check(lib.e3d_adamw_step_dyn(
+                        tab["pptr"].data_ptr(), tab["gptr"].data_ptr(), tab["mptr"].data_ptr(), tab["vptr"].data_ptr(),
+                        tab["numel"].data_ptr(), tab["chunk_tensor"].data_ptr() + 4 * c0, tab["chunk_first"].data_ptr() + 8 * c0,
+                        c1 - c0, nc.data_ptr() if nc is not None else None, tab["dyn"].data_ptr() + 8 * r, float(b1), float(b2),
+                        float(group["eps"]), float(group["weight_decay"]), stream), "e3d_adamw_step_dyn")
+                    continue
                 hip.check(lib.e3d_adamw_step(
                     tab["pptr"].data_ptr(), tab["gptr"].data_ptr(), tab["mptr"].data_ptr(), tab["vptr"].data_ptr(),
                     tab["numel"].data_ptr(), tab["chunk_tensor"].data_ptr() + 4 * c0, tab["chunk_first"].data_ptr() + 8 * c0,
                     c1 - c0, nc.data_ptr() if nc is not None else None, float(lr), float(b1), float(b2), float(group["eps"]),
                     float(group["weight_decay"]), step + 1, stream), "e3d_adamw_step")
             tab["ranges"][k] = [(c0, c1, step + 1) for (c0, c1, step) in tab["ranges"][k]]
+        if self.device_scalars:
+            tab["dyn"][:, 1] += 1.0                      # the device-side step counts (captured with the step)
         torch._foreach_add_(tab["step_tensors"], 1)
         return loss
 
@@ -157,12 +205,19 @@ class ClipAdamW(torch.optim.AdamW):
             "vptr": dev_i64([self.state[p]["exp_avg_sq"].data_ptr() for p in params]),
             "numel": dev_i64([p.numel() for p in params]),
             "chunk_tensor": torch.tensor(chunk_tensor, dtype=torch.int32).to(dev), "chunk_first": dev_i64(chunk_first),
-            "n_chunks": n_chunks, "ranges": ranges, "gptr_host": None, "gptr": None,
+            "n_chunks": n_chunks, "ranges": ranges, "gptr_host": None,
+            "gptr": torch.zeros(len(params), dtype=torch.int64, device=dev),
+            "gptr_pin": torch.zeros(len(params), dtype=torch.int64).pin_memory(),
             "partial": torch.empty(n_chunks, dtype=torch.float32, device=dev),
             "norm_and_clip": torch.zeros(2, dtype=torch.float32, device=dev),
             "step_tensors": [self.state[p]["step"] for p in params],
             # (the state tensors the device tables point into: kept alive with the tables)
             "keep": [(self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in params],
         }
+        if self.device_scalars:
+            flat = [(gi, c0, st) for (gi, _), rs in zip(parts, ranges) for (c0, c1, st) in rs]
+            tab["dyn_ranges"] = flat
+            tab["dyn_lr"] = [float(self.param_groups[gi]["lr"]) for gi, _, _ in flat]
+            tab["dyn"] = torch.tensor([[lr, float(st)] for lr, (_, _, st) in zip(tab["dyn_lr"], flat)], dtype=torch.float32).to(dev)
         self._e3d_tab = tab
         return tab

@@ -47,7 +47,9 @@ class PredefinedNoiseScheduleDiscrete(torch.nn.Module):
 
     def get_alpha_bar(self, t_normalized=None, t_int=None):
         idx = self._index(t_normalized, t_int)
-        return self.alphas_bar.to(idx.device)[idx]
+        if self.alphas_bar.device != idx.device:      # moved once (a per-call .to() is a synchronising copy)
+            self.alphas_bar = self.alphas_bar.to(idx.device)
+        return self.alphas_bar[idx]
 
 
 class DiscreteUniformTransition:

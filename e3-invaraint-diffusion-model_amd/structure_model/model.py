@@ -142,7 +142,15 @@ class ConditionalBertForDiffusion(ConditionalBertForDiffusionBase):
                 groups.setdefault(key, []).append(i)
             terms = [None] * n_feat
             for idx in groups.values():
-                e = elems[idx[0]](predicted_noise[..., idx], known_noise[..., idx])          # [B, L, len(idx)]
+                if idx == list(range(idx[0], idx[-1] + 1)):                   # a run of features: plain slices
+                    pn, kn = predicted_noise[..., idx[0]:idx[-1] + 1], known_noise[..., idx[0]:idx[-1] + 1]
+                else:                                                         # (index tensors are made once per device)
+                    cache = self.__dict__.setdefault("_e3d_loss_idx", {})
+                    it = cache.get((tuple(idx), predicted_noise.device))
+                    if it is None:
+                        it = cache[(tuple(idx), predicted_noise.device)] = torch.tensor(idx, device=predicted_noise.device)
+                    pn, kn = predicted_noise.index_select(-1, it), known_noise.index_select(-1, it)
+                e = elems[idx[0]](pn, kn)                                     # [B, L, len(idx)]
                 sums = torch.where(sel, e, torch.zeros((), dtype=e.dtype, device=e.device)).sum(dim=(0, 1)) / count
                 for j, i in enumerate(idx):
                     terms[i] = sums[j]

@@ -64,6 +64,96 @@ def clip_and_step(params, optim, max_norm, fold=None):
     return norm
 
 
+class GraphedStep:
+    """One training step -- ``training_step`` + backward with deferred weight gradients + gradient-norm clip + AdamW -- as
+    a HIP graph: captured once per batch signature (tensor names, shapes, dtypes) after ``warmup`` eager steps, then
+    replayed.  The eager step of the structure model needs ~25 ms of Python and launch calls for ~1 350 kernels that keep
+    the GPU busy for ~27 ms: replaying removes the host from the step.
+
+    What makes the step replayable: no device-to-host synchronisation inside it (the losses are masked means, not index
+    lists); the learning rate and the AdamW step counts live in device memory (``ClipAdamW.use_device_scalars``); dropout
+    decisions take a device-side epoch word on top of their baked seeds (``ops.dropout_epoch``), advanced inside the graph;
+    derived-weight caches (W^T, distance-table planes) are refreshed by launches inside the captured backward / forward.
+    Batches with another signature (a ragged last batch) run eagerly.  Single process only: the RCCL collectives of the
+    data-parallel step stay outside graphs."""
+
+    def __init__(self, model, optim, params, gradient_clip, warmup=2):
+        from .optim import ClipAdamW
+        if not isinstance(optim, ClipAdamW):
+            raise TypeError("GraphedStep needs optim.ClipAdamW (device-side learning rate and step counts)")
+        self.model, self.optim, self.params, self.clip = model, optim, params, gradient_clip
+        self.warmup, self.seen = warmup, {}
+        self.graph = self.key = self.static = self.loss = None
+        self.failed = None
+        optim.use_device_scalars(True)
+        self.epoch = ops.dropout_epoch(params[0].device)
+
+    def _body(self, batch, batch_idx=0):
+        loss = self.model.training_step(batch, batch_idx)
+        self.optim.zero_grad(set_to_none=True)
+        if DEFER_WEIGHT_GRADS:
+            with autograd.deferred_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
+        clip_and_step(self.params, self.optim, self.clip)
+        return loss
+
+    @staticmethod
+    def _signature(batch):
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+
+    def _capture(self, batch):
+        dev = self.params[0].device
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        import gc
+        gc.collect()                                 # autograd graphs of earlier steps (and their AccumulateGrad nodes) gone
+        torch.cuda.synchronize(dev)
+        self.optim.zero_grad(set_to_none=True)       # the gradients of the replayed step live in the graph's pool
+        self.optim.sync_lr()
+        graph = torch.cuda.CUDAGraph()
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:      # AccumulateGrad nodes of the eager steps meet the capture stream once: expected here
+            quiet(False)
+        try:
+            with torch.cuda.graph(graph):
+                loss = self._body(self.static)
+                self.epoch.add_(1)
+        finally:
+            if quiet is not None:
+                quiet(True)
+        self.graph, self.loss = graph, loss
+        self.optim.note_replayed_step(-1)            # capture ran step()'s host bookkeeping without executing anything
+
+    def step(self, batch, batch_idx=0):
+        """Returns the loss (a device tensor; for a replayed step it is overwritten by the next replay)."""
+        key = self._signature(batch)
+        if self.failed is None and self.graph is None and self.seen.get(key, 0) >= self.warmup:
+            try:
+                self._capture(batch)                # (records, does not execute: this batch runs as the first replay below)
+                self.key = key
+            except Exception as e:                  # noqa: BLE001 -- any capture failure: stay eager, say so once
+                self.failed = e
+                self.graph = None
+                import traceback
+                import warnings
+                warnings.warn(f"training step could not be captured in a HIP graph, staying eager: {e!r}\n"
+                              + "".join(traceback.format_exc(limit=-6)))
+        if self.graph is not None and key == self.key:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self.static[k].copy_(v, non_blocking=True)
+            self.optim.sync_lr()
+            self.graph.replay()
+            self.optim.note_replayed_step()
+            ops.invalidate_weight_caches()
+            return self.loss
+        self.seen[key] = self.seen.get(key, 0) + 1
+        loss = self._body(batch, batch_idx).detach()   # (detached: a live autograd graph would keep its AccumulateGrad nodes,
+        self.epoch.add_(1)                             #  bound to this stream, alive into the capture)
+        return loss
+
+
 def move_batch(batch, device):
     return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
@@ -90,6 +180,8 @@ class BestCheckpoint:
 # E3D_TRAIN_ARITHMETIC=bf16 (opt-in): the reference's own training precision -- plain bf16 products in every GEMM (forward,
 # input and weight gradients), bf16x3 in the attention kernels; ~1e-2-grade gradients instead of ~1e-4-grade.
 TRAIN_ARITHMETIC = os.environ.get("E3D_TRAIN_ARITHMETIC", "bf16x3")
+# single-process training replays the step from a HIP graph (GraphedStep); 0: eager steps
+GRAPH_TRAIN = os.environ.get("E3D_TRAIN_GRAPH", "1") == "1"
 DEFER_WEIGHT_GRADS = os.environ.get("E3D_DEFER_WGRAD", "1") == "1"   # autograd.deferred_weight_grads in the step
 
 
@@ -116,6 +208,11 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
     ckpt = BestCheckpoint(checkpoint_path, checkpoint_mode)
     history = {"train_loss": [], "val_loss": [], "steps": 0, "seconds": 0.0}
     params = [p for p in model.parameters() if p.requires_grad]
+    stepper = None
+    if GRAPH_TRAIN and world == 1 and params and params[0].is_cuda and not averager._active():
+        from .optim import ClipAdamW
+        if isinstance(optim, ClipAdamW):
+            stepper = GraphedStep(model, optim, params, gradient_clip)
     t0 = time.perf_counter()
     step = 0
     for epoch in range(max_epochs):
@@ -125,6 +222,17 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
         losses = []
         for batch_idx, batch in enumerate(train_loader):
             batch = move_batch(batch, device)
+            if stepper is not None:
+                loss = stepper.step(batch, batch_idx)
+                if sched is not None and sched.get("interval") == "step":
+                    sched["scheduler"].step()
+                losses.append(float(loss.detach()))
+                step += 1
+                if rank == 0 and log_every_n_steps and step % log_every_n_steps == 0:
+                    log(f"epoch {epoch} step {step} train_loss {losses[-1]:.5f}")
+                if max_steps is not None and step >= max_steps:
+                    break
+                continue
             loss = model.training_step(batch, batch_idx)
             optim.zero_grad(set_to_none=True)
             averager.prepare()                       # grads as views of the all-reduce buckets (no-op for one process)

@@ -221,3 +221,116 @@ def test_clip_adamw_three_launch_step_matches_torch(pkg, hip):
             opt.step()
         for x, y in zip(pa, pb):
             assert torch.allclose(x, y, rtol=2e-6, atol=1e-7)
+
+
+def _small_structure_model(dropout=0.0, seed=0):
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as M
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=64,
+             hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    torch.manual_seed(seed)
+    m = M(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("abcdefgh"),
+          loss_func=[M.diheral_loss_func] * 4 + [M.angle_loss_func] * 4, l2_lambda=0.1, learning_rate=1e-3)
+    with torch.no_grad():       # adaLN_modulation[0] is zero-initialised: give the gated branches weights
+        for se in (m.receptor_emb, m.timestep_emb):
+            torch.nn.init.normal_(se.adaLN_modulation[0].weight, std=0.02)
+    return m.train().to("cuda:0")
+
+
+def _structure_batches(n, B=8, L=64):
+    from helpers import synthetic_pockets
+    from e3diff_amd.structure_model.dataset import noise_batch_on_device
+    from e3diff_amd.structure_model.utils import CosineTables
+    tab = CosineTables(100)
+    out = []
+    for i in range(n):
+        b = B if i != 4 else B - 3                                   # one ragged batch: runs eagerly between replays
+        pk = {k: v.to("cuda:0") for k, v in synthetic_pockets(b, L, seed=10 + i).items() if torch.is_tensor(v)}
+        g = torch.Generator().manual_seed(500 + i)
+        t = torch.randint(0, 100, (b, 1), generator=g).to("cuda:0")
+        noise = torch.randn(b, L, 8, generator=g).to("cuda:0")
+        out.append(dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab, timestep=t, noise=noise)))
+    return out
+
+
+def test_graph_replayed_training_step_matches_the_eager_step(pkg, hip):
+    """training.GraphedStep (what ``training.fit`` runs for a single process): two eager steps, capture, replays -- against
+    plain eager steps on a twin model with the same batches: per-step losses and the parameters after 8 steps agree, with a
+    learning rate that changes every step (device-side scalar), a ragged batch in the middle (eager, then replays again) and
+    the optimizer's step counts where torch's AdamW would have them."""
+    from e3diff_amd import autograd, ops, training
+    batches = _structure_batches(8)
+    results = []
+    for graphed in (False, True):
+        model = _small_structure_model()
+        optim = model.configure_optimizers()["optimizer"]
+        params = [p for p in model.parameters() if p.requires_grad]
+        stepper = training.GraphedStep(model, optim, params, 1.0) if graphed else None
+        losses = []
+        with ops.arithmetic("bf16x3"):
+            for k, batch in enumerate(batches):
+                optim.param_groups[0]["lr"] = 1e-3 * (1 + 0.25 * k)
+                if graphed:
+                    losses.append(float(stepper.step(batch)))
+                else:
+                    loss = model.training_step(batch)
+                    optim.zero_grad(set_to_none=True)
+                    with autograd.deferred_weight_grads():
+                        loss.backward()
+                    training.clip_and_step(params, optim, 1.0)
+                    losses.append(float(loss))
+        if graphed:
+            assert stepper.graph is not None and stepper.failed is None
+        assert {int(st["step"]) for st in optim.state.values()} == {8}
+        results.append((losses, [p.detach().clone() for p in params]))
+    (la, pa), (lb, pb) = results
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(la, lb)), (la, lb)
+    # parameters: AdamW turns a gradient element that is zero up to rounding into a +-lr step, so single elements may differ
+    # between ANY two runs (small split-K weight-gradient launches sum with atomics); the bulk must agree -- mean difference
+    # against the mean distance travelled from the common initial values
+    p0 = [p.detach().clone() for p in _small_structure_model().parameters() if p.requires_grad]
+    moved = sum(float((a - z).abs().sum()) for a, z in zip(pa, p0))
+    apart = sum(float((a - b).abs().sum()) for a, b in zip(pa, pb))
+    assert moved > 0 and apart < 0.02 * moved, (apart, moved)
+
+
+def test_graph_replays_draw_fresh_dropout_decisions(pkg, hip):
+    """With the reference's dropout (0.1) every replay of the captured step must drop different elements: the seeds are baked
+    into the graph, the device-side epoch word is what moves.  Same batch every step: the losses of consecutive replays
+    differ, stay finite, and forward / backward still agree (the step keeps learning on the repeated batch)."""
+    from e3diff_amd import ops, training
+    batch = _structure_batches(1)[0]
+    model = _small_structure_model(dropout=0.1)
+    optim = model.configure_optimizers()["optimizer"]
+    params = [p for p in model.parameters() if p.requires_grad]
+    stepper = training.GraphedStep(model, optim, params, 1.0)
+    e0 = int(ops.dropout_epoch("cuda:0"))
+    with ops.arithmetic("bf16x3"):
+        losses = [float(stepper.step(batch)) for _ in range(40)]
+    assert stepper.graph is not None and int(ops.dropout_epoch("cuda:0")) == e0 + 40
+    assert all(l == l and abs(l) < 1e3 for l in losses)
+    assert len({round(l, 6) for l in losses[3:9]}) == 6                 # replays are not copies of each other
+    assert sum(losses[-5:]) < sum(losses[2:7])                         # and the model learns the repeated batch
+
+
+def test_graph_replays_redraw_the_sequence_models_timesteps_and_noise(pkg, hip):
+    """PeptideDiff.training_step draws t and the categorical noise with torch's device generator INSIDE the step
+    (sequence_model/model.py:347-367): under graph replay the generator's offset must advance per replay -- the same batch
+    gives a different loss every replay (dropout off, tiny learning rate), all finite."""
+    from helpers import synthetic_pockets
+    from e3diff_amd import ops, training
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=64,
+             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = PeptideDiff(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("ACDEFGHIKLMNPQRSTVWY"),
+                        loss_func=torch.nn.CrossEntropyLoss(), noise_schedule="cosine", timesteps=50, l2_lambda=0.1, lr=1e-7).train().to("cuda:0")
+    optim = model.configure_optimizers()["optimizer"]
+    params = [p for p in model.parameters() if p.requires_grad]
+    batch = {k: v.to("cuda:0") for k, v in synthetic_pockets(8, 64, seed=3, with_ligand_seq=True).items() if torch.is_tensor(v)}
+    stepper = training.GraphedStep(model, optim, params, 1.0)
+    with ops.arithmetic("bf16x3"):
+        losses = [float(stepper.step(batch)) for _ in range(10)]
+    assert stepper.graph is not None and stepper.failed is None
+    assert all(l == l and abs(l) < 1e4 for l in losses) and len({round(l, 5) for l in losses[3:]}) >= 6, losses

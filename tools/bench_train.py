@@ -24,7 +24,7 @@ DEV = "cuda:0"
 
 
 def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2, device=DEV, ddp=False, layers=None,
-        seed=0, arithmetic=None):
+        seed=0, arithmetic=None, graph=None):
     """One GPU's training step of BASELINE config 2 (structure, B=32) / config 4 (sequence, B=64): forward + loss +
     backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict.
     ``ddp``: the step of ``training.fit`` under an initialised process group (BASELINE config 4: one rank per GPU,
@@ -61,11 +61,19 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         sharding.broadcast_parameters(model, src=0)
         averager = sharding.GradientAverager(model.parameters())
 
+    # as training.fit does for a single process: the step replayed from a HIP graph (training.GraphedStep) after two eager
+    # steps; ``graph=False`` / E3D_TRAIN_GRAPH=0: eager
+    graph = (pkg.training.GRAPH_TRAIN if graph is None else graph) and not ddp and isinstance(optim, pkg.optim.ClipAdamW)
+    stepper = pkg.training.GraphedStep(model, optim, params, 1.0) if graph else None
+    warmup = max(warmup, 4) if graph else warmup
+
     def step():
         if model_name == "structure":
             batch_ = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab))
         else:
             batch_ = pk
+        if stepper is not None:
+            return stepper.step(batch_)
         loss = model.training_step(batch_)
         optim.zero_grad(set_to_none=True)
         if averager is not None:
@@ -84,7 +92,8 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
     with pkg.ops.arithmetic(arithmetic or pkg.training.TRAIN_ARITHMETIC):   # bf16x3 unless E3D_GEMM_MODE says otherwise
         mode = pkg.ops.GEMM_MODE
         for _ in range(warmup):
-            step()
+            loss = step()
+        del loss
         torch.cuda.synchronize()
         if ddp and dist.is_initialized():
             dist.barrier()
@@ -114,7 +123,8 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
         dist.all_gather(ws, w)
         assert all(float(t) == float(ws[0]) for t in ws), "ranks diverged"
     return {"model": model_name, "batch": B, "seq_len": L, "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
-            "arithmetic": mode, "dropout": dropout, "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "host_enqueue_ms": host_ms,
+            "arithmetic": mode, "dropout": dropout, "graph_replay": bool(stepper is not None and stepper.graph is not None),
+            "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "host_enqueue_ms": host_ms,
             **({"ranks": dist.get_world_size(), "global_batch": B * dist.get_world_size(),
                 "global_samples_per_s": B * dist.get_world_size() / dt, "backend": dist.get_backend(),
                 "gradient_MB_per_step": sum(p.numel() for p in params) * 4 / 1e6,
@@ -129,11 +139,13 @@ def main():
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
+    ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step")
     ap.add_argument("--arithmetic", default=None, help="bf16x3 (default) | bf16x6 | bf16 = plain bf16 products, the reference's own training precision")
     args = ap.parse_args()
-    r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout, arithmetic=args.arithmetic)
+    r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout, arithmetic=args.arithmetic,
+            graph=False if args.eager else None)
     print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} layers={r['layers']} params={r['params_M']:.1f}M "
-          f"gemm_mode={r['arithmetic']} dropout={r['dropout']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
+          f"gemm_mode={r['arithmetic']} dropout={r['dropout']} graph={r['graph_replay']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
           f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB; host enqueue {r['host_enqueue_ms']:.1f} ms)", flush=True)
 
 
