@@ -130,6 +130,7 @@ class _TiedPack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w_packed, b_packed, n, *parts):
         ctx.n, ctx.rows = n, [p.shape[0] for p in parts[:n]]
+        ctx.set_materialize_grads(False)      # deferred weight gradients hand back None: no zero tensors, no zero accumulation
         return w_packed.view(w_packed.shape), b_packed.view(b_packed.shape)
 
     @staticmethod
