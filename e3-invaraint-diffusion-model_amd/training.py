@@ -124,10 +124,19 @@ class GraphedStep:
                 quiet(True)
         self.graph, self.loss = graph, loss
         self.optim.note_replayed_step(-1)            # capture ran step()'s host bookkeeping without executing anything
+        self.tab = self.optim._e3d_tab               # the optimizer tables (parameter / moment pointers) the graph baked
+        self.ptrs = [p.data_ptr() for p in self.params]
+
+    def _stale(self):
+        """The graph carries raw pointers: parameters that moved (``module.to()``) or optimizer state that was replaced
+        (``load_state_dict``: ClipAdamW drops its tables) invalidate it -- warm up and capture again."""
+        return self.optim._e3d_tab is not self.tab or any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
 
     def step(self, batch, batch_idx=0):
         """Returns the loss (a device tensor; for a replayed step it is overwritten by the next replay)."""
         key = self._signature(batch)
+        if self.graph is not None and self._stale():
+            self.graph, self.key, self.seen = None, None, {}
         if self.failed is None and self.graph is None and self.seen.get(key, 0) >= self.warmup:
             try:
                 self._capture(batch)                # (records, does not execute: this batch runs as the first replay below)
