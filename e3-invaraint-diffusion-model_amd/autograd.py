@@ -131,10 +131,69 @@ class deferred_weight_grads:
                     if last_slice[id(p)] == si:
                         self.on_param(p)
 
+    # One launch for layers of different shapes / strides (e3d_gemm_wgrad_ragged_f32_split); 0: one launch per
+    # (shape, stride) group as in round 2 (A/B runs)
+    RAGGED = os.environ.get("E3D_WGRAD_RAGGED", "1") == "1"
+
+    def _flush_ragged(self, items, M, terms, touched):
+        """All queued layers of one token count, 64 per launch, whatever their shapes and row strides."""
+        import ctypes
+        lib = hip.lib()
+        tiles = sum((-(-it[0].shape[1] // 256)) * (-(-it[1].shape[1] // 128)) for it in items)
+        if tiles < self.MIN_TILES:
+            for dz, x, w, b in items:
+                self._single(dz, x, w, b, dz.shape[1], x.shape[1], M)
+                touched[id(w)] = w
+                if b is not None:
+                    touched[id(b)] = b
+            return
+        mixed = [it for it in items if it[3] is not None and (it[2].grad is None) != (it[3].grad is None)]
+        for dz, x, w, b in mixed:     # one accumulate bit per problem covers weight and bias: these take the per-layer path
+            self._single(dz, x, w, b, dz.shape[1], x.shape[1], M)
+            touched[id(w)] = w
+            touched[id(b)] = b
+        if mixed:
+            items = [it for it in items if not any(it is m for m in mixed)]
+        for lo in range(0, len(items), 64):
+            chunk = items[lo:lo + 64]
+            n = len(chunk)
+            a_dz, a_x, a_dw, a_db = ((ctypes.c_void_p * n)() for _ in range(4))
+            a_n, a_k = (ctypes.c_int * n)(), (ctypes.c_int * n)()
+            a_ldz, a_ldx = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)()
+            bits = 0
+            for i, (dz, x, w, b) in enumerate(chunk):
+                gw, acc_w = self._grad_buffer(w)
+                a_dz[i], a_x[i], a_dw[i] = dz.data_ptr(), x.data_ptr(), gw.data_ptr()
+                if b is not None:
+                    gb, acc_b = self._grad_buffer(b)
+                    assert acc_b == acc_w
+                    a_db[i] = gb.data_ptr()
+                a_n[i], a_k[i], a_ldz[i], a_ldx[i] = dz.shape[1], x.shape[1], dz.stride(0), x.stride(0)
+                bits |= int(acc_w) << i
+                touched[id(w)] = w
+                if b is not None:
+                    touched[id(b)] = b
+            hip.check(lib.e3d_gemm_wgrad_ragged_f32_split(a_dz, a_x, a_dw, a_db, a_n, a_k, a_ldz, a_ldx, bits, n, M, terms,
+                                                          _stream()), "e3d_gemm_wgrad_ragged_f32_split")
+
     def _flush_slice(self, pending):
         import ctypes
         terms = ops.GEMM_MODES[ops.GEMM_MODE] or 6
         lib = hip.lib()
+        if self.RAGGED:
+            # a weight used more than once in the forward pass: its later uses go to later rounds (a launch must not hold
+            # two problems with the same output), each adding to what the earlier rounds wrote
+            rounds, seen, touched = [], {}, {}
+            for item in pending:
+                r = seen.get(id(item[2]), 0)
+                seen[id(item[2])] = r + 1
+                while len(rounds) <= r:
+                    rounds.append({})
+                rounds[r].setdefault(item[0].shape[0], []).append(item)       # by token count
+            for by_m in rounds:
+                for M, items in by_m.items():
+                    self._flush_ragged(items, M, terms, touched)
+            return touched
         # a weight used more than once in the forward pass: its later uses go to later rounds (a launch must not
         # hold two problems with the same output), each adding to what the earlier rounds wrote
         rounds, seen = [], {}
@@ -279,6 +338,17 @@ def _refresh_transposes(entries):
             dst = (ctypes.c_void_p * len(chunk))(*[c[1] for c in chunk])
             hip.check(hip.lib().e3d_transpose_grouped_f32(src, dst, len(chunk), rows, cols, cols, ld_dst, _stream()),
                       "e3d_transpose_grouped_f32")
+
+
+def forget_transposes(keep):
+    """Drop every registered W^T whose parameters are not all in ``keep`` (a set of ``id(parameter)``).  A training step
+    about to be captured into a graph calls this (training.GraphedStep): the refresh that the first stale use triggers
+    covers EVERY stale entry of the registry, and a captured step must not bake launches that read another model's
+    weights and write buffers that die with that model."""
+    for key in list(_WT_REGISTRY):
+        ps = _WT_REGISTRY[key].parts()
+        if ps is None or not all(id(p) in keep for p in ps):
+            del _WT_REGISTRY[key]
 
 
 def _transposed_weight(weight):

@@ -546,6 +546,40 @@ __global__ __launch_bounds__(512) void gemm_wgrad_grouped_kernel(const WgradGrou
                                                                         g.db[p], (int)((g.accumulate >> p) & 1));
 }
 
+// The same launch for layers of DIFFERENT shapes and row strides (one token count): a model's weight gradients then need
+// ceil(layers / 64) launches whose grids are whole multiples of the chip but for one tail, instead of one launch per
+// (shape, stride) group with a partial last round each (structure model: 22 rounds of 256 workgroups for 17.3 rounds of
+// tiles).  Problem p owns tiles [tile_start[p], tile_start[p + 1]); a workgroup finds its problem by bisection over the
+// kernel-argument table (wave-uniform: scalar loads).
+struct WgradRagged {
+    const float* dz[64];
+    const float* x[64];
+    float* dw[64];
+    float* db[64];                   // may be null per problem (no bias)
+    int N[64], K[64], ldz[64], ldx[64];
+    int tile_start[65];
+    unsigned long long accumulate;
+};
+static_assert(sizeof(WgradRagged) <= 3400, "kernel arguments are limited to 4 KB");
+
+template <int NS, bool TR>
+__global__ __launch_bounds__(512) void gemm_wgrad_ragged_kernel(const WgradRagged g, int M, int count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lid = xcd_remap(blockIdx.x, g.tile_start[count]);
+    int lo = 0, hi = count;          // the largest p with tile_start[p] <= lid
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g.tile_start[mid] <= lid) lo = mid;
+        else hi = mid;
+    }
+    const int p = lo, N = g.N[p], K = g.K[p];
+    const int tiles_m = (N + 255) / 256, tiles_n = (K + 127) / 128;
+    gemm_split_body<NS, E3D_ACT_NONE, true, true, 4, 2, __bf16, 2, TR>(smem_raw, g.dz[p], (int64_t)g.ldz[p], g.x[p], (int64_t)g.ldx[p],
+                                                                        nullptr, g.dw[p], K, N, K, M, tiles_m, tiles_n, M,
+                                                                        lid - g.tile_start[p], 0, 1, g.db[p],
+                                                                        (int)((g.accumulate >> p) & 1));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Large-M forward variant: 256x256x32 workgroup tile, 8 waves as 2(M) x 4(N), each wave 128x64
 // (4x2 MFMA tiles, 128 accumulator registers).  Versus the 256x128 kernel it moves 2/3 of the
@@ -1210,6 +1244,58 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
         else go(gemm_wgrad_grouped_kernel<3, false>, lds, ok3);
     }
     return e3d_launch_status("e3d_gemm_wgrad_grouped_f32_split");
+}
+
+extern "C" int e3d_gemm_wgrad_ragged_f32_split(const float* const* dz, const float* const* x, float* const* dw, float* const* db,
+                                               const int* N, const int* K, const int64_t* ldz, const int64_t* ldx,
+                                               uint64_t accumulate_bits, int count, int M, int terms, void* stream) {
+    E3D_REQUIRE(dz && x && dw && N && K && ldz && ldx && count >= 1 && count <= 64, "gemm_wgrad_ragged: 1..64 problems (count=%d)", count);
+    E3D_REQUIRE(M > 0, "gemm_wgrad_ragged: bad token count %d", M);
+    E3D_REQUIRE(terms == E3D_TERMS_BF16 || terms == 3 || terms == 6 || terms == E3D_TERMS_F16X3,
+                "gemm_wgrad_ragged: terms must be 1, 3, 6 or 19 (got %d)", terms);
+    WgradRagged g;
+    static const bool tr_on = !getenv("E3D_WGRAD_TR") || atoi(getenv("E3D_WGRAD_TR")) != 0;
+    bool tr = tr_on;
+    int64_t tiles = 0;
+    for (int p = 0; p < 64; ++p) {
+        const int q = p < count ? p : 0;
+        E3D_REQUIRE(dz[q] && x[q] && dw[q], "gemm_wgrad_ragged: null pointer in problem %d", q);
+        E3D_REQUIRE(N[q] > 0 && K[q] > 0 && ldz[q] >= N[q] && ldx[q] >= K[q] && ldz[q] < (1ll << 31) && ldx[q] < (1ll << 31),
+                    "gemm_wgrad_ragged: bad shape in problem %d: N=%d K=%d ldz=%lld ldx=%lld", q, N[q], K[q], (long long)ldz[q],
+                    (long long)ldx[q]);
+        g.dz[p] = dz[q]; g.x[p] = x[q]; g.dw[p] = dw[q]; g.db[p] = db ? db[q] : nullptr;
+        g.N[p] = N[q]; g.K[p] = K[q]; g.ldz[p] = (int)ldz[q]; g.ldx[p] = (int)ldx[q];
+        g.tile_start[p] = (int)tiles;
+        if (p < count) {
+            tiles += (int64_t)((N[q] + 255) / 256) * ((K[q] + 127) / 128);
+            tr = tr && N[q] % 4 == 0 && K[q] % 4 == 0 && ldz[q] % 4 == 0 && ldx[q] % 4 == 0 && ((uintptr_t)dz[q] % 16) == 0 &&
+                 ((uintptr_t)x[q] % 16) == 0;
+        }
+    }
+    E3D_REQUIRE(tiles < (1ll << 30), "gemm_wgrad_ragged: too many tiles");
+    for (int p = count; p <= 64; ++p) g.tile_start[p] = (int)tiles;
+    g.accumulate = accumulate_bits;
+    const dim3 grid((unsigned)tiles), block(512);
+    hipStream_t s = (hipStream_t)stream;
+    auto go = [&](auto kern, size_t lds, std::atomic<uint64_t>& lds_ok) {
+        e3d_allow_lds(lds_ok, kern, lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, g, M, count);
+    };
+    static std::atomic<uint64_t> ok1{0}, ok1t{0}, ok2{0}, ok2t{0}, ok3{0}, ok3t{0};
+    if (terms == E3D_TERMS_BF16) {
+        const size_t lds = (size_t)2 * 1 * (256 + 128) * ROW_B;
+        if (tr) go(gemm_wgrad_ragged_kernel<1, true>, lds, ok1t);
+        else go(gemm_wgrad_ragged_kernel<1, false>, lds, ok1);
+    } else if (terms == 3) {
+        const size_t lds = (size_t)2 * 2 * (256 + 128) * ROW_B;
+        if (tr) go(gemm_wgrad_ragged_kernel<2, true>, lds, ok2t);
+        else go(gemm_wgrad_ragged_kernel<2, false>, lds, ok2);
+    } else {
+        const size_t lds = (size_t)1 * 3 * (256 + 128) * ROW_B;
+        if (tr) go(gemm_wgrad_ragged_kernel<3, true>, lds, ok3t);
+        else go(gemm_wgrad_ragged_kernel<3, false>, lds, ok3);
+    }
+    return e3d_launch_status("e3d_gemm_wgrad_ragged_f32_split");
 }
 
 extern "C" int e3d_gemm_bias_act_f32_split(const float* A, int64_t lda, const float* W,

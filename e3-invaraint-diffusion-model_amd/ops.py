@@ -236,6 +236,7 @@ def f16_weight(weight):
 SKINNY_MAX_M = 1024 if os.environ.get("E3D_GEMM_SKINNY", "1") == "1" else 0
 SKINNY_MAX_TILES = 768
 _SKINNY_WS = {}
+_SKINNY_RETIRED = []
 
 
 def _skinny_workspace(device, M, N, K):
@@ -243,7 +244,10 @@ def _skinny_workspace(device, M, N, K):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _SKINNY_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        # (under a graph capture this comes from the graph's private pool and is kept alive here: replay-safe)
+        # (under a graph capture this comes from the graph's private pool and is kept alive here: replay-safe; a workspace
+        #  that is outgrown is parked, not freed -- an earlier capture on this stream may have baked its address)
+        if ws is not None:
+            _SKINNY_RETIRED.append(ws)
         ws = _SKINNY_WS[key] = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=device)
     return ws
 

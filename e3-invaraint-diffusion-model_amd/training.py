@@ -108,6 +108,7 @@ class GraphedStep:
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         import gc
         gc.collect()                                 # autograd graphs of earlier steps (and their AccumulateGrad nodes) gone
+        autograd.forget_transposes({id(p) for p in self.model.parameters()})   # nothing of another model in this graph
         torch.cuda.synchronize(dev)
         self.optim.zero_grad(set_to_none=True)       # the gradients of the replayed step live in the graph's pool
         self.optim.sync_lr()
@@ -235,10 +236,10 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
                 loss = stepper.step(batch, batch_idx)
                 if sched is not None and sched.get("interval") == "step":
                     sched["scheduler"].step()
-                losses.append(float(loss.detach()))
+                losses.append(loss.detach().clone())     # (a replayed step's loss tensor is overwritten by the next replay)
                 step += 1
                 if rank == 0 and log_every_n_steps and step % log_every_n_steps == 0:
-                    log(f"epoch {epoch} step {step} train_loss {losses[-1]:.5f}")
+                    log(f"epoch {epoch} step {step} train_loss {float(losses[-1]):.5f}")
                 if max_steps is not None and step >= max_steps:
                     break
                 continue
@@ -257,14 +258,17 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             ops.invalidate_weight_caches()           # belt and braces beside the global optimizer hook (ops.py)
             if sched is not None and sched.get("interval") == "step":
                 sched["scheduler"].step()
-            losses.append(float(loss.detach()))
+            losses.append(loss.detach())
             step += 1
             if rank == 0 and log_every_n_steps and step % log_every_n_steps == 0:
-                log(f"epoch {epoch} step {step} train_loss {losses[-1]:.5f}")
+                log(f"epoch {epoch} step {step} train_loss {float(losses[-1]):.5f}")
             if max_steps is not None and step >= max_steps:
                 break
         if sched is not None and sched.get("interval") == "epoch":
             sched["scheduler"].step()
+        # the per-step losses stay on the device until here: a float() per step would make the host wait for every step
+        # (Lightning reads the loss for its progress bar every step; the values of the logged steps are the same)
+        losses = torch.stack(losses).double().cpu().tolist() if losses else []
         mean_train = sum(losses) / max(1, len(losses))
         history["train_loss"].append(mean_train)
         if rank == 0:

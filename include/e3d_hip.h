@@ -278,6 +278,14 @@ int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const float* const*
                                      uint64_t accumulate_bits, int count, int64_t ldz, int64_t ldx, int N, int K, int M,
                                      int terms, void* stream);
 
+/* The same launch for layers of DIFFERENT shapes and row strides over ONE token count M (ABI v3): problem p is
+ * dW_p[N[p], K[p]] = dz_p^T x_p with row strides ldz[p] / ldx[p]; ``db`` (and single entries of it) may be NULL.  A model's
+ * weight gradients then take ceil(layers / 64) launches whose grids fill the chip in whole rounds but for one tail, instead
+ * of one launch per (shape, stride) group with a partial last round each. */
+int e3d_gemm_wgrad_ragged_f32_split(const float* const* dz, const float* const* x, float* const* dw, float* const* db,
+                                    const int* N, const int* K, const int64_t* ldz, const int64_t* ldx,
+                                    uint64_t accumulate_bits, int count, int M, int terms, void* stream);
+
 /* Backward of e3d_relkey_attn_fwd.  out / lse are the forward's outputs, dout [B,Lq,nh*64].
  * Writes dq, dk, dv (strided like q, k, v) and, with dist_emb, d_dist_emb [2P-1,64] (overwritten).
  * workspace: e3d_relkey_attn_bwd_workspace_floats(...) floats (materialised P and dS tiles + the

@@ -98,6 +98,48 @@ def test_grouped_weight_gradients(pkg, hip, N, K, M, count, mode, tol):
     assert all(torch.equal(a, b) for a, b in zip(keep, db))
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16x6", 1e-5)])
+def test_ragged_weight_gradients_of_mixed_shapes_in_one_launch(pkg, hip, mode, tol):
+    """e3d_gemm_wgrad_ragged_f32_split: layers of different shapes and row strides (one token count) in ONE launch -- a
+    packed-QKV column block (stride 2304), square and rectangular weights, a ragged one (N, K not multiples of the tile
+    nor of 4: the launch then takes the dword staging), problems without a bias, the accumulate bit -- against fp64, and
+    bit-identical between two launches."""
+    import ctypes
+    lib = pkg.hip.lib()
+    terms = pkg.ops.GEMM_MODES[mode]
+    for M, shapes in ((1000, [(768, 768, 2304), (768, 768, 768), (1024, 768, 1024), (768, 1024, 768), (1536, 768, 1536), (64, 96, 64)]),
+                      (515, [(300, 160, 364), (768, 768, 768), (302, 162, 302)])):
+        count = len(shapes)
+        wide = [torch.randn(M, ld, generator=g(10 + p)).to(DEV) for p, (N, K, ld) in enumerate(shapes)]
+        dz = [w[:, :N] for w, (N, K, ld) in zip(wide, shapes)]
+        x = [torch.randn(M, K, generator=g(100 + p)).to(DEV) for p, (N, K, ld) in enumerate(shapes)]
+        bits = sum(1 << p for p in range(count) if p % 3 == 1)
+        no_bias = {2}
+        outs = []
+        for rep in range(2):
+            dw = [torch.full((N, K), float(p), device=DEV) for p, (N, K, ld) in enumerate(shapes)]
+            db = [torch.full((N,), -float(p), device=DEV) for p, (N, K, ld) in enumerate(shapes)]
+            arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])   # noqa: E731
+            a_db = (ctypes.c_void_p * count)(*[None if p in no_bias else db[p].data_ptr() for p in range(count)])
+            ints = lambda vals, ty: (ty * count)(*vals)   # noqa: E731
+            pkg.hip.check(lib.e3d_gemm_wgrad_ragged_f32_split(
+                arr(dz), arr(x), arr(dw), a_db, ints([s_[0] for s_ in shapes], ctypes.c_int), ints([s_[1] for s_ in shapes], ctypes.c_int),
+                ints([t.stride(0) for t in dz], ctypes.c_int64), ints([t.stride(0) for t in x], ctypes.c_int64), bits, count, M, terms,
+                torch.cuda.current_stream().cuda_stream), "ragged wgrad")
+            outs.append(dw + db)
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+        for p, (N, K, ld) in enumerate(shapes):
+            want_w = dz[p].double().t() @ x[p].double()
+            want_b = dz[p].double().sum(0)
+            if bits >> p & 1:
+                want_w, want_b = want_w + p, want_b - p
+            assert rel_err(outs[0][p], want_w.float()) < tol, (M, p)
+            if p in no_bias:
+                assert torch.equal(outs[0][count + p], torch.full((N,), -float(p), device=DEV))
+            else:
+                assert rel_err(outs[0][count + p], want_b.float()) < 1e-5, (M, p)
+
+
 def test_gemm_general_odd_reduction_and_strided(pkg, hip):
     from e3diff_amd.autograd import gemm_general
     M, N, K = 70, 200, 45          # K-major operands: any K, any N
