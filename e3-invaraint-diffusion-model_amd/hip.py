@@ -45,6 +45,12 @@ _SIGNATURES = {
                                            c_int, c_int, c_int, _P]),
     "e3d_transpose_grouped_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int64, _P]),
     "e3d_gemm_wgrad_grouped_f32_split": (c_int, [_P, _P, _P, _P, c_uint64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
+    # deferred LayerNorm (inference, large M)
+    "e3d_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_int64]),
+    "e3d_gemm_bias_act_f32_split_ln": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_float,
+                                               _P, _P, c_int64, _P, _P, _P, _P]),
+    "e3d_row_stats_f32": (c_int, [_P, c_float, _P, c_int, c_int, _P]),
+    "e3d_layernorm_from_stats_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "e3d_gemm_wgrad_ragged_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_uint64, c_int, c_int, c_int, _P]),
     "e3d_relkey_attn_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "e3d_relkey_attn_bwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,
