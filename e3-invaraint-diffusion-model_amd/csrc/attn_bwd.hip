@@ -411,7 +411,7 @@ extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs
     }
     }
     if (dist_emb) {
-        hipError_t e = hipMemsetAsync(d_dist_emb, 0, (size_t)(2 * P - 1) * D * sizeof(float), s);
+        hipError_t e = e3d_zero_async(d_dist_emb, (size_t)(2 * P - 1) * D, s);
         E3D_REQUIRE(e == hipSuccess, "attn_bwd: memset failed: %s", hipGetErrorString(e));
         const int n_units = B * nh * q_tiles, upb = 64;
         hipLaunchKernelGGL(dist_emb_reduce_kernel, dim3(2 * P - 1, (n_units + upb - 1) / upb), dim3(64), 0, s, part,

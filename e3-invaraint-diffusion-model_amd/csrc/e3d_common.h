@@ -64,6 +64,25 @@ static inline void e3d_allow_lds(std::atomic<uint64_t>& mask, K kernel, size_t l
     });
 }
 
+// Zero-fill by a kernel launch.  hipMemsetAsync nodes inside a captured graph did not clear their destinations reliably on
+// this stack (tools/lab/graph_stale_pointer_hunt.py: gradients accumulated by atomics on top of whatever the buffer held);
+// a kernel node always runs where it was captured.
+static __global__ void e3d_zero_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline hipError_t e3d_zero_async(float* p, size_t n_floats, hipStream_t s) {
+    if (n_floats == 0) return hipSuccess;
+    const size_t blocks = (n_floats + 1023) / 1024;
+    hipLaunchKernelGGL(e3d_zero_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, p, n_floats);
+    return hipGetLastError();
+}
+// rows x cols floats of a matrix with row stride ld (floats)
+static __global__ void e3d_zero2d_kernel(float* __restrict__ p, size_t ld, size_t rows, size_t cols) {
+    const size_t n = rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + i % cols] = 0.f;
+}
+
 static inline int e3d_launch_status(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

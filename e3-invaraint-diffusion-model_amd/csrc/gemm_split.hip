@@ -1157,8 +1157,11 @@ int launch_general(const float* A, int64_t lda, const float* B, int64_t ldb, con
         k_chunk = ((K + splits - 1) / splits + BK - 1) / BK * BK;
         splits = (K + k_chunk - 1) / k_chunk;
         hipError_t e = hipSuccess;
-        if (ldc == N) e = hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), s);
-        else e = hipMemset2DAsync(out, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+        if (ldc == N) e = e3d_zero_async(out, (size_t)M * N, s);
+        else {
+            hipLaunchKernelGGL(e3d_zero2d_kernel, dim3(1024), dim3(256), 0, s, out, (size_t)ldc, (size_t)M, (size_t)N);
+            e = hipGetLastError();
+        }
         if (e != hipSuccess) {
             e3d_set_error("gemm_split: split-K memset failed: %s", hipGetErrorString(e));
             return (int)e;

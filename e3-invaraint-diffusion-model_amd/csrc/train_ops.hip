@@ -383,10 +383,10 @@ extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* g
     E3D_REQUIRE(dy && s && ds && M > 0, "layernorm_bwd: bad arguments");
     hipError_t e = hipSuccess;
     if (dgamma && dbeta == dgamma + H) {   // one buffer (autograd.layernorm_bwd allocates them so): one memset
-        e = hipMemsetAsync(dgamma, 0, (size_t)2 * H * sizeof(float), (hipStream_t)stream);
+        e = e3d_zero_async(dgamma, (size_t)2 * H, (hipStream_t)stream);
     } else {
-        if (dgamma) e = hipMemsetAsync(dgamma, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
-        if (e == hipSuccess && dbeta) e = hipMemsetAsync(dbeta, 0, (size_t)H * sizeof(float), (hipStream_t)stream);
+        if (dgamma) e = e3d_zero_async(dgamma, (size_t)H, (hipStream_t)stream);
+        if (e == hipSuccess && dbeta) e = e3d_zero_async(dbeta, (size_t)H, (hipStream_t)stream);
     }
     E3D_REQUIRE(e == hipSuccess, "layernorm_bwd: memset failed: %s", hipGetErrorString(e));
     const int blocks = (M + 15) / 16 < 512 ? (M + 15) / 16 : 512;
@@ -425,7 +425,7 @@ extern "C" int e3d_act_bwd(const float* dh, const float* z, int act, float* dz, 
 extern "C" int e3d_colsum(const float* x, int64_t ld, float* out, int M, int N, void* stream) {
     E3D_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    hipError_t e = e3d_zero_async(out, (size_t)N, s);
     E3D_REQUIRE(e == hipSuccess, "colsum: memset failed: %s", hipGetErrorString(e));
     // ~1024 blocks of 256 columns x rpb rows
     const int col_blocks = (N + 255) / 256;
@@ -465,8 +465,8 @@ extern "C" int e3d_small_k_wgrad(const float* g, const float* x, float* dW, floa
                                  int transpose_out, void* stream) {
     E3D_REQUIRE(g && x && dW && M > 0 && H > 0 && F >= 1 && F <= 32, "small_k_wgrad: bad arguments (F=%d)", F);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dW, 0, (size_t)H * F * sizeof(float), s);
-    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)H * sizeof(float), s);
+    hipError_t e = e3d_zero_async(dW, (size_t)H * F, s);
+    if (e == hipSuccess && db) e = e3d_zero_async(db, (size_t)H, s);
     E3D_REQUIRE(e == hipSuccess, "small_k_wgrad: memset failed: %s", hipGetErrorString(e));
     const int rpb = 256;   // = the kernel's LDS tile of x rows
     hipLaunchKernelGGL(small_k_wgrad_kernel, dim3((H + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, g, x, dW, db, M,

@@ -87,6 +87,11 @@ class GraphedStep:
         self.failed = None
         optim.use_device_scalars(True)
         self.epoch = ops.dropout_epoch(params[0].device)
+        # ONE side stream for the eager steps and for the capture: autograd binds an AccumulateGrad node to the stream
+        # it was created on and keeps synchronising with that stream for as long as the node lives; eager steps on the
+        # caller's stream followed by a capture on another one left the captured graph with unordered work (seen as
+        # garbage gradients a few hundred replays in: tools/lab/train_soak.py)
+        self.stream = torch.cuda.Stream(device=params[0].device)
 
     def _body(self, batch, batch_idx=0):
         loss = self.model.training_step(batch, batch_idx)
@@ -117,7 +122,7 @@ class GraphedStep:
         if quiet is not None:      # AccumulateGrad nodes of the eager steps meet the capture stream once: expected here
             quiet(False)
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=self.stream):
                 loss = self._body(self.static)
                 self.epoch.add_(1)
         finally:
@@ -159,8 +164,13 @@ class GraphedStep:
             ops.invalidate_weight_caches()
             return self.loss
         self.seen[key] = self.seen.get(key, 0) + 1
-        loss = self._body(batch, batch_idx).detach()   # (detached: a live autograd graph would keep its AccumulateGrad nodes,
-        self.epoch.add_(1)                             #  bound to this stream, alive into the capture)
+        cur = torch.cuda.current_stream(self.stream.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            loss = self._body(batch, batch_idx).detach()
+            self.epoch.add_(1)
+        cur.wait_stream(self.stream)
+        loss.record_stream(cur)
         return loss
 
 

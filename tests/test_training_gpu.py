@@ -271,7 +271,15 @@ def test_graph_replayed_training_step_matches_the_eager_step(pkg, hip):
             for k, batch in enumerate(batches):
                 optim.param_groups[0]["lr"] = 1e-3 * (1 + 0.25 * k)
                 if graphed:
+                    # freed caching-allocator blocks full of a poison value between replays: a captured step that reads
+                    # memory it does not own (hipMemsetAsync nodes did not clear their destinations reliably inside a
+                    # captured graph: the bias / LayerNorm gradients, summed by atomics, then started from whatever the
+                    # allocator had there) shows up as a garbage gradient norm
+                    junk = [torch.full((n,), 1.2345e30, device="cuda:0") for n in (64, 768, 4096, 65536, 1 << 20, 1 << 22)]
+                    del junk
+                    torch.cuda.synchronize()
                     losses.append(float(stepper.step(batch)))
+                    assert float(optim.last_norm) < 1e3, (k, float(optim.last_norm))
                 else:
                     loss = model.training_step(batch)
                     optim.zero_grad(set_to_none=True)
@@ -336,3 +344,62 @@ def test_graph_replays_redraw_the_sequence_models_timesteps_and_noise(pkg, hip):
         losses = [float(stepper.step(batch)) for _ in range(10)]
     assert stepper.graph is not None and stepper.failed is None
     assert all(l == l and abs(l) < 1e4 for l in losses) and len({round(l, 5) for l in losses[3:]}) >= 6, losses
+
+
+def test_captured_step_reads_no_memory_it_does_not_own(pkg, hip):
+    """After a training step has been captured, EVERY free block of the caching allocator's default pool is claimed and
+    filled with a poison value; one replay later the gradient norm must still be sane.  (Found with
+    tools/lab/graph_stale_pointer_hunt.py: hipMemsetAsync nodes inside the captured graph did not clear their destinations
+    reliably, so the bias / LayerNorm / embedding gradients -- summed by atomics on top of the memset -- picked up whatever
+    the allocator had handed out around them: correct for hundreds of replays, then 1e30.  The zero-fills are kernel
+    launches now.)  Full model width, two layers: the sizes at which it showed."""
+    from helpers import synthetic_pockets
+    from e3diff_amd import ops, training
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.structure_model.dataset import noise_batch_on_device
+    from e3diff_amd.structure_model.model import ConditionalBertForDiffusion as M
+    from e3diff_amd.structure_model.utils import CosineTables
+    dev, L, B = "cuda:0", 128, 32
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=2, max_position_embeddings=L,
+             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = M(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("abcdefgh"),
+              loss_func=[M.diheral_loss_func] * 4 + [M.angle_loss_func] * 4, l2_lambda=0.1, learning_rate=1e-4).train().to(dev)
+    tab = CosineTables(1000)
+    optim = model.configure_optimizers()["optimizer"]
+    params = [p for p in model.parameters() if p.requires_grad]
+    stepper = training.GraphedStep(model, optim, params, 1.0)
+    pk = {k: v.to(dev) for k, v in synthetic_pockets(B, L, seed=0).items() if torch.is_tensor(v)}
+
+    def free_blocks():
+        out = []
+        for seg in torch.cuda.memory_snapshot():
+            if tuple(seg.get("segment_pool_id", (0, 0))) != (0, 0):
+                continue
+            out += [(b["size"], seg.get("stream", 0)) for b in seg["blocks"] if b["state"] == "inactive"]
+        return out
+
+    with ops.arithmetic("bf16x3"):
+        for _ in range(4):
+            stepper.step(dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab)))
+        assert stepper.graph is not None and stepper.failed is None
+        sane = float(optim.last_norm)
+        batch = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab))
+        torch.cuda.synchronize()
+        held = []
+        for _ in range(6):
+            fb = sorted(free_blocks(), reverse=True)
+            if sum(sz for sz, _ in fb) < (1 << 16):
+                break
+            for size, stream in fb:
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()):
+                    held.append(torch.empty(max(1, (size - 256) // 4), dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()
+        for t in held:
+            t.fill_(1.2345e30)
+        torch.cuda.synchronize()
+        assert len(held) > 4
+        stepper.step(batch)
+        norm = float(optim.last_norm)
+    assert 0.1 * sane < norm < 10 * sane, (sane, norm)
+    assert all(bool((t == 1.2345e30).all()) for t in held)        # and it wrote into none of them
