@@ -99,6 +99,9 @@ class ClipAdamW(torch.optim.AdamW):
         if not parts:
             self.last_norm = None
             return loss
+        if len({p.device for _, ps in parts for p in ps}) != 1:      # one pointer table = one device
+            self._fallback(None)
+            return loss
         tab = self._tables(parts)
         lib = hip.lib()
         dev = tab["device"]
