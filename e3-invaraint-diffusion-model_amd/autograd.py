@@ -275,13 +275,20 @@ def act_bwd(dh, z, act):
     return dz
 
 
-def layernorm_bwd(dy, s, gamma, eps, want_affine_grads=True):
+def layernorm_bwd(dy, s, gamma, eps, want_affine_grads=True, drop=None):
+    """``drop`` = (p, seed) of a dropout folded into the forward (ops.residual_layernorm(..., drop=)): returns
+    (ds, dg, db, ds_dropped) -- ds_dropped = dropout(ds, p, seed), the gradient of the dropped-out input."""
     M, H = s.shape
     ds = torch.empty_like(s)
     dg = db = None
-    if want_affine_grads:      # one allocation: the C side then zeroes both with one memset
+    if want_affine_grads:      # one allocation: the C side then zeroes both with one fill
         both = torch.empty((2, H), device=s.device, dtype=torch.float32)
         dg, db = both[0], both[1]
+    if drop is not None:
+        dsd = torch.empty_like(s)
+        hip.check(hip.lib().e3d_layernorm_bwd_drop(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dsd), _p(dg), _p(db), M, H,
+                                                   float(drop[0]), int(drop[1]), _stream()), "e3d_layernorm_bwd_drop")
+        return ds, dg, db, dsd
     hip.check(hip.lib().e3d_layernorm_bwd(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dg), _p(db), M, H, _stream()),
               "e3d_layernorm_bwd")
     return ds, dg, db
@@ -499,9 +506,13 @@ class _Dropout(torch.autograd.Function):
 
 
 class _ResidualLayerNorm(torch.autograd.Function):
+    """LayerNorm(dropout(x) + residual): ``p_drop`` > 0 folds the nn.Dropout that follows the dense layer of
+    BertSelfOutput / BertOutput into the LayerNorm kernels (no [M, H] dropout pass in either direction)."""
+
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps):
-        out, s = ops.residual_layernorm(x, residual, gamma, beta, eps, want_s=True)
+    def forward(ctx, x, residual, gamma, beta, eps, p_drop=0.0):
+        ctx.drop = (float(p_drop), ops.next_dropout_seed()) if p_drop and p_drop > 0 else None
+        out, s = ops.residual_layernorm(x, residual, gamma, beta, eps, want_s=True, drop=ctx.drop)
         ctx.save_for_backward(s, gamma)
         ctx.eps, ctx.has_res = eps, residual is not None
         return out
@@ -509,8 +520,11 @@ class _ResidualLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         s, gamma = ctx.saved_tensors
+        if ctx.drop is not None:
+            ds, dg, db, dsd = layernorm_bwd(dy.contiguous(), s, gamma, ctx.eps, drop=ctx.drop)
+            return dsd, (ds if ctx.has_res else None), dg, db, None, None
         ds, dg, db = layernorm_bwd(dy.contiguous(), s, gamma, ctx.eps)
-        return ds, (ds if ctx.has_res else None), dg, db, None
+        return ds, (ds if ctx.has_res else None), dg, db, None, None
 
 
 class _AdaLNGate(torch.autograd.Function):
@@ -570,6 +584,10 @@ class _HeadLinear(torch.autograd.Function):
         return dx, dW, colsum(dout)
 
 
+# nn.Dropout after BertSelfOutput.dense / BertOutput.dense inside the residual-LayerNorm kernels (0: its own launches, A/B runs)
+FUSE_HIDDEN_DROPOUT = os.environ.get("E3D_FUSE_HIDDEN_DROPOUT", "1") == "1"
+
+
 # ----------------------------------------------------------------------------- functional front-end
 def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
@@ -614,10 +632,12 @@ class functional:
         return ops.dropout(x.contiguous(), p, ops.next_dropout_seed())
 
     @staticmethod
-    def residual_layernorm(x, residual, gamma, beta, eps):
+    def residual_layernorm(x, residual, gamma, beta, eps, p_drop=0.0):
+        """LayerNorm(dropout(x, p_drop) + residual)."""
         if _needs_grad(x, residual, gamma, beta):
-            return _ResidualLayerNorm.apply(x, residual, gamma, beta, eps)
-        return ops.residual_layernorm(x, residual, gamma, beta, eps)
+            return _ResidualLayerNorm.apply(x, residual, gamma, beta, eps, p_drop)
+        drop = (float(p_drop), ops.next_dropout_seed()) if p_drop and p_drop > 0 else None
+        return ops.residual_layernorm(x, residual, gamma, beta, eps, drop=drop)
 
     @staticmethod
     def linear_residual_layernorm(x, weight, bias, residual, gamma, beta, eps, p_drop=0.0):
@@ -626,6 +646,8 @@ class functional:
         if not p_drop and not _needs_grad(x, weight, bias, residual, gamma, beta):
             return ops.linear_residual_layernorm(x, weight, bias, residual, gamma, beta, eps)
         fn = functional
+        if FUSE_HIDDEN_DROPOUT:
+            return fn.residual_layernorm(fn.linear(x, weight, bias), residual, gamma, beta, eps, p_drop)
         return fn.residual_layernorm(fn.dropout(fn.linear(x, weight, bias), p_drop), residual, gamma, beta, eps)
 
     @staticmethod

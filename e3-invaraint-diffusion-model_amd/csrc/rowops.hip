@@ -39,16 +39,29 @@ __device__ __forceinline__ void row_normalize(f32x4 (&r)[V], float eps) {
     for (int i = 0; i < V; ++i) r[i] *= rstd;
 }
 
-template <int V>
+// DROP: x is the output of a dense layer that nn.Dropout follows (BertSelfOutput / BertOutput in training mode): the
+// multipliers of e3d_dropout_f32 for the same (p, seed) -- element index = row * H + column -- are applied as x is read,
+// instead of by a pass of their own over the [M, H] tensor
+template <int V, bool DROP = false>
 __global__ __launch_bounds__(256) void residual_layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ s_out, float* __restrict__ out, int M) {
+    const float* __restrict__ beta, float eps, float* __restrict__ s_out, float* __restrict__ out, int M, E3dDrop drop_in = E3dDrop{}) {
     constexpr int H = 256 * V;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     f32x4 r[V], t[V];
     row_load<V>(r, x + (int64_t)row * H, lane);
+    if (DROP) {
+        const E3dDrop drop = e3d_drop_resolve(drop_in);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float m[4];
+            e3d_drop_mult4(drop, (uint64_t)row * (H / 4) + 64 * i + lane, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[i][j] *= m[j];
+        }
+    }
     if (res) {
         row_load<V>(t, res + (int64_t)row * H, lane);
 #pragma unroll
@@ -283,6 +296,18 @@ extern "C" int e3d_residual_layernorm_fwd(const float* x, const float* residual,
     DISPATCH_V(H, hipLaunchKernelGGL(residual_layernorm_kernel<V>, grid, block, 0, (hipStream_t)stream, x,
                                      residual, gamma, beta, eps, s_out, out, M));
     return e3d_launch_status("e3d_residual_layernorm_fwd");
+}
+
+extern "C" int e3d_residual_layernorm_drop_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                                               float eps, float* s_out, float* out, int M, int H, float drop_p, uint64_t drop_seed,
+                                               void* stream) {
+    E3D_REQUIRE(x && gamma && beta && out && M > 0, "residual_layernorm_drop: bad arguments");
+    E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "residual_layernorm_drop: p = %f", (double)drop_p);
+    const dim3 grid((M + 3) / 4), block(256);
+    const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
+    DISPATCH_V(H, hipLaunchKernelGGL((residual_layernorm_kernel<V, true>), grid, block, 0, (hipStream_t)stream, x, residual, gamma,
+                                     beta, eps, s_out, out, M, d));
+    return e3d_launch_status("e3d_residual_layernorm_drop_fwd");
 }
 
 extern "C" int e3d_row_stats_f32(const float* z, float eps, float* stats, int M, int H, void* stream) {

@@ -68,14 +68,29 @@ __device__ __forceinline__ void ln_input_grad(f32x4 (&g)[V], const f32x4 (&xhat)
 // ---------------------------------------------------------------- LayerNorm backward
 // Each wave walks rows wave_id, wave_id + n_waves, ...; dgamma/dbeta partials stay in registers, are
 // summed over the block in LDS and added once per block (float atomics: order-dependent last bits).
-template <int V>
+// DROP: the LayerNorm's first input was dropout(x) (e3d_residual_layernorm_drop_fwd): besides ds (the gradient of the
+// pre-norm sum = of the residual) the kernel writes ds * multipliers (the gradient of x) to ``dsd``
+template <int V, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
                                                             const float* __restrict__ s,
                                                             const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ ds, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int M) {
+                                                            float* __restrict__ dbeta, int M, float* __restrict__ dsd = nullptr,
+                                                            E3dDrop drop_in = E3dDrop{}) {
     constexpr int H = 256 * V;
     const int lane = threadIdx.x & 63;
+    const E3dDrop drop = DROP ? e3d_drop_resolve(drop_in) : drop_in;
+    auto store_dropped = [&](const f32x4 (&g)[V], int row) {
+        f32x4 d[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float m[4];
+            e3d_drop_mult4(drop, (uint64_t)row * (H / 4) + 64 * i + lane, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = g[i][j] * m[j];
+        }
+        row_store<V>(d, dsd + (int64_t)row * H, lane);
+    };
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     f32x4 ga[V], acc_g[V], acc_b[V];
     if (gamma) row_load<V>(ga, gamma, lane);
@@ -100,6 +115,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         ln_input_grad<V>(g, x, rstd);
         row_store<V>(g, ds + (int64_t)row * H, lane);
+        if (DROP) store_dropped(g, row);
         if (two) {
             const float rstd2 = row_normalize<V>(x2, eps);
 #pragma unroll
@@ -110,6 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
             ln_input_grad<V>(g2, x2, rstd2);
             row_store<V>(g2, ds + (int64_t)row2 * H, lane);
+            if (DROP) store_dropped(g2, row2);
         }
     }
     // the block's 4 waves reduce through LDS first: one atomic per column per block
@@ -393,6 +410,25 @@ extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* g
     DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s,
                                      gamma, eps, ds, dgamma, dbeta, M));
     return e3d_launch_status("e3d_layernorm_bwd");
+}
+
+extern "C" int e3d_layernorm_bwd_drop(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
+                                      float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, void* stream) {
+    E3D_REQUIRE(dy && s && ds && ds_dropped && M > 0, "layernorm_bwd_drop: bad arguments");
+    E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd_drop: p = %f", (double)drop_p);
+    hipError_t e = hipSuccess;
+    if (dgamma && dbeta == dgamma + H) {
+        e = e3d_zero_async(dgamma, (size_t)2 * H, (hipStream_t)stream);
+    } else {
+        if (dgamma) e = e3d_zero_async(dgamma, (size_t)H, (hipStream_t)stream);
+        if (e == hipSuccess && dbeta) e = e3d_zero_async(dbeta, (size_t)H, (hipStream_t)stream);
+    }
+    E3D_REQUIRE(e == hipSuccess, "layernorm_bwd_drop: zero-fill failed: %s", hipGetErrorString(e));
+    const int blocks = (M + 15) / 16 < 512 ? (M + 15) / 16 : 512;
+    const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
+    DISPATCH_V(H, hipLaunchKernelGGL((layernorm_bwd_kernel<V, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s, gamma,
+                                     eps, ds, dgamma, dbeta, M, ds_dropped, d));
+    return e3d_launch_status("e3d_layernorm_bwd_drop");
 }
 
 extern "C" int e3d_adaln_gate_bwd(const float* dout, const float* y, const float* mod, int branch,

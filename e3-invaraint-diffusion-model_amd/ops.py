@@ -498,7 +498,9 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
     return (out, lse) if want_lse else out
 
 
-def residual_layernorm(x, residual, gamma, beta, eps, want_s=False):
+def residual_layernorm(x, residual, gamma, beta, eps, want_s=False, drop=None):
+    """LayerNorm(x + residual); ``drop`` = (p, seed): LayerNorm(dropout(x) + residual) with the multipliers of
+    ``dropout(x, p, seed)`` applied inside the kernel."""
     for n, t in (("x", x), ("residual", residual), ("gamma", gamma), ("beta", beta)):
         _chk(t, "residual_layernorm." + n)
     assert x.is_contiguous() and (residual is None or residual.is_contiguous())
@@ -506,8 +508,13 @@ def residual_layernorm(x, residual, gamma, beta, eps, want_s=False):
     out = torch.empty_like(x)
     s = torch.empty_like(x) if want_s else None
     with _timed("residual_layernorm", (M, H)):
-        hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s),
-                                                       _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
+        if drop is not None and drop[0] > 0:
+            hip.check(hip.lib().e3d_residual_layernorm_drop_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s), _p(out), M, H,
+                                                                float(drop[0]), int(drop[1]), _stream()),
+                      "e3d_residual_layernorm_drop_fwd")
+        else:
+            hip.check(hip.lib().e3d_residual_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), eps, _p(s),
+                                                           _p(out), M, H, _stream()), "e3d_residual_layernorm_fwd")
     return (out, s) if want_s else out
 
 

@@ -388,6 +388,16 @@ int e3d_small_k_wgrad(const float* g, const float* x, float* dW, float* db, int 
 int e3d_head_linear_bwd_dx(const float* dout, const float* W, float* dx, int M, int H, int Nout,
                            void* stream);
 
+/* nn.Dropout between the dense layer and the residual LayerNorm of BertSelfOutput / BertOutput (training mode; transformers
+ * 4.38.2 modeling_bert.py) folded into the LayerNorm kernels: the forward applies the multipliers of e3d_dropout_f32 for
+ * the same (p, seed) to x as it reads it (element index = row * H + column), the backward writes both ds (gradient of the
+ * pre-norm sum = of the residual) and ds_dropped = ds * multipliers (gradient of x): no [M, H] dropout pass in either
+ * direction.  Same (p, seed) in both calls. */
+int e3d_residual_layernorm_drop_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float eps,
+                                    float* s_out, float* out, int M, int H, float drop_p, uint64_t drop_seed, void* stream);
+int e3d_layernorm_bwd_drop(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
+                           float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, void* stream);
+
 /* ---- deferred LayerNorm (ABI v3; inference at large M) ------------------------------------------------------------------
  * BertSelfOutput / BertOutput compute LayerNorm(dense(x) + residual) (transformers 4.38.2 modeling_bert.py; the reference
  * runs them through structure_model/model.py:180-215): at M = 65536 rows that LayerNorm is a 600-MB pass of its own after

@@ -154,3 +154,24 @@ def test_model_dropout_is_active_in_training_only_and_seedable(pkg, hip):
     t1.square().mean().backward()                    # gradients flow through every dropout site
     grads = [p.grad for n, p in model.named_parameters() if p.grad is not None]
     assert grads and all(torch.isfinite(gr).all() for gr in grads)
+
+
+@pytest.mark.parametrize("M,H", [(70, 768), (4096, 768), (33, 256)])
+def test_dropout_folded_into_the_residual_layernorm_kernels(pkg, hip, M, H):
+    """LayerNorm(dropout(x) + r) with the dropout applied INSIDE the LayerNorm kernels: forward and both input gradients
+    are bit-identical to the separate dropout launch followed by the plain kernels for the same (p, seed)."""
+    from e3diff_amd import autograd as AG, ops
+    g = torch.Generator().manual_seed(5)
+    x, r = torch.randn(M, H, generator=g).cuda(), torch.randn(M, H, generator=g).cuda()
+    ga, be = (1 + 0.1 * torch.randn(H, generator=g)).cuda(), torch.randn(H, generator=g).cuda()
+    dy = torch.randn(M, H, generator=g).cuda()
+    p, seed = 0.1, 987654321
+    out_f, s_f = ops.residual_layernorm(x, r, ga, be, 1e-12, want_s=True, drop=(p, seed))
+    out_u, s_u = ops.residual_layernorm(ops.dropout(x, p, seed), r, ga, be, 1e-12, want_s=True)
+    assert torch.equal(out_f, out_u) and torch.equal(s_f, s_u)
+    ds_f, dg_f, db_f, dsd = AG.layernorm_bwd(dy, s_f, ga, 1e-12, drop=(p, seed))
+    ds_u, dg_u, db_u = AG.layernorm_bwd(dy, s_u, ga, 1e-12)
+    assert torch.equal(ds_f, ds_u) and torch.equal(dsd, ops.dropout(ds_u, p, seed))
+    for a, b in ((dg_f, dg_u), (db_f, db_u)):          # (summed by atomics: order-dependent last bits)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    assert not torch.equal(out_f, ops.residual_layernorm(x, r, ga, be, 1e-12))                                # it does drop
