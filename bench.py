@@ -482,7 +482,7 @@ def main():
                             "sequence_B64_L128": bench_train.run("sequence", steps=10),
                             "structure_B32_L128_eager": bench_train.run("structure", steps=5, graph=False),
                             "note": "forward + loss + backward + grad-norm clip + AdamW, 12+12 / 6 layers x 768, synthetic "
-                                    "batches, dropout 0 (the reference's 0.1 costs +1.5 ms); the step as training.fit runs it "
+                                    "batches, dropout 0 (the reference's 0.1 costs +0.7 ms); the step as training.fit runs it "
                                     "for one process: captured into a HIP graph after two eager steps and replayed "
                                     "(graph_replay; host_enqueue_ms = Python time per step); *_eager = the same step "
                                     "launch by launch"}
