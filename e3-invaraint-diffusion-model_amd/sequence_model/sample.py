@@ -12,6 +12,8 @@ if __package__ in (None, ""):  # executed as a script from inside this directory
     _g.load_package()
     __package__ = "e3diff_amd.sequence_model"
 
+import os
+
 import torch
 from torch.nn import functional as F
 from torch.utils.data import DataLoader
@@ -122,9 +124,64 @@ def sample_p_zs_given_zt_discrete(t, s, noised_data, pred_noise, noise_schedule,
     return F.one_hot(idx.long(), num_classes=C).float()
 
 
+class GraphedDenoiseStep:
+    """One reverse step of the sequence chain -- ``model.forward`` + ``sample_p_zs_given_zt_discrete`` -- captured once
+    into a HIP graph and replayed per step, as structure_model/sample.py::GraphedReverseStep does for the angle chain.
+    What varies between steps lives on the device: the step index ``self.s`` ([B,1] float: both normalised times, the
+    schedule look-ups and the timestep embedding are computed from it inside the graph), the state ``self.x`` and the
+    uniforms of the categorical draw (drawn inside the graph, or injected through ``self.u``).  The last step of a chain
+    (which returns the raw logits) is not replayed.  Small chains are host-bound when launched kernel by kernel (about
+    150 launches per step): default for at most ``GRAPH_MAX_ROWS`` token rows, ``use_graph`` / E3D_SAMPLE_GRAPH override."""
+
+    def __init__(self, model, x_like, ligand_angles, ligand_mask, receptor_seq, receptor_angles, receptor_mask, noise_schedule,
+                 transition, diverse, T, inject_u=False):
+        dev = x_like.device
+        self.args = (ligand_angles, ligand_mask, receptor_seq, receptor_angles, receptor_mask)
+        self.model, self.schedule, self.transition, self.diverse, self.T = model, noise_schedule, transition, diverse, T
+        self.x = x_like.clone()
+        self.s = torch.zeros((x_like.shape[0], 1), device=dev)
+        self.u = torch.zeros(x_like.shape[:2], device=dev) if (inject_u and diverse) else None
+        self.out = None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):       # warm-up off the capture: first-launch attribute calls, caches, allocator
+            self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+
+    def _body(self):
+        logits = self.model.forward(self.s, self.x, *self.args)
+        return sample_p_zs_given_zt_discrete((self.s + 1) / self.T, self.s / self.T, self.x, logits, self.schedule, self.transition,
+                                             self.diverse, is_last_step=False, u=self.u)
+
+    def step(self, s_int, x, u=None):
+        """z_t -> z_s for the step index ``s_int`` (> 0); returns the graph's output buffer (overwritten by the next call)."""
+        if (u is not None) != (self.u is not None):
+            raise ValueError("this graph was captured %s injected uniforms" % ("with" if self.u is not None else "without"))
+        self.s.fill_(float(s_int))
+        if x is not self.x:
+            self.x.copy_(x)
+        if u is not None:
+            self.u.copy_(u)
+        self.graph.replay()
+        return self.out
+
+
+GRAPH_MAX_ROWS = 512      # token rows (B x L) up to which a chain replays a captured graph by default
+
+
+def _use_graph(x):
+    env = os.environ.get("E3D_SAMPLE_GRAPH")
+    if env in ("0", "1"):
+        return env == "1"
+    return x.shape[0] * x.shape[1] <= GRAPH_MAX_ROWS
+
+
 @torch.no_grad()
 def denoise(batch, model: PeptideDiff, noise_schedule, transition, diverse, x_T=None, us=None,
-            generated_angles=None, timesteps=None, trim_padding=False):
+            generated_angles=None, timesteps=None, trim_padding=False, use_graph=None):
     """Full reverse chain over CONFIG["timesteps"] steps + recovery metrics (reference
     sample.py:181-229).  ``x_T`` / ``us`` inject the initial one-hot noise and the per-step
     uniforms (parity tests); ``generated_angles`` replaces the dataset's ligand angles
@@ -150,7 +207,19 @@ def denoise(batch, model: PeptideDiff, noise_schedule, transition, diverse, x_T=
         receptor_mask = receptor_mask[:, :Lr].contiguous()
         if us is not None:
             us = [u[:, :Ll] if u is not None and u.dim() >= 2 else u for u in us]
+    graphed = None
+    if (_use_graph(x) if use_graph is None else use_graph) and T > 4:
+        try:
+            graphed = GraphedDenoiseStep(model, x, ligand_angles.contiguous(), ligand_mask, receptor_seq, receptor_angles, receptor_mask,
+                                         noise_schedule, transition, diverse, T, inject_u=us is not None)
+        except Exception as e:   # noqa: BLE001 -- any capture problem: eager launches are always correct
+            import warnings
+            warnings.warn(f"HIP-graph capture of the sequence reverse step failed ({type(e).__name__}: {e}); using eager launches")
     for n, s_int in enumerate(reversed(range(T))):
+        if graphed is not None and s_int > 0:
+            u_n = None if us is None else us[n]
+            x = graphed.step(s_int, x, None if u_n is None else u_n.to(dev).float())
+            continue
         s_array = s_int * torch.ones((B, 1), device=dev)
         t_array = s_array + 1
         logits = model.forward(s_array, x, ligand_angles, ligand_mask, receptor_seq, receptor_angles, receptor_mask)

@@ -183,3 +183,35 @@ def test_joint_handover_helpers(pkg, hip):
     mask = (torch.arange(16)[None] < torch.tensor([[5], [9]])).float().to(DEV)
     out = angles_from_trajectory(traj, mask)
     assert torch.equal(out[0, :5], traj[-1, 0, :5]) and float(out[0, 5:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("diverse", [False, True])
+def test_denoise_graph_replay_is_bit_identical_to_eager_launches(pkg, hip, diverse):
+    """sequence_model/sample.py::denoise with the reverse step replayed from a HIP graph (GraphedDenoiseStep: default for
+    small chains) against kernel-by-kernel launches: the same sequences and recovery rates for the argmax chain and for the
+    categorical chain with injected uniforms (a discrete chain: ONE different class would change every later step), and
+    the graph really is what ran."""
+    from e3diff_amd.sequence_model import sample as S
+    from e3diff_amd.sequence_model.utils import BlosumTransition, PredefinedNoiseScheduleDiscrete
+    cfg = dict(FULL_SEQ, num_hidden_layers=2)
+    B, L, T = 4, 64, 12
+    model, _ = build(pkg, cfg, L, seed=21)
+    pk = synthetic_pockets(B, L, seed=6, with_ligand_seq=True)
+    gen = torch.Generator().manual_seed(4)
+    x_T = F.one_hot(torch.randint(0, 20, (B, L), generator=gen), 20).float()
+    us = [u.to(DEV) for u in torch.rand(T, B, L, generator=gen)] if diverse else None
+    sched, trans = PredefinedNoiseScheduleDiscrete("cosine", T).to(DEV), BlosumTransition(x_classes=20)
+    made = []
+    orig = S.GraphedDenoiseStep.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+    S.GraphedDenoiseStep.__init__ = spy
+    try:
+        outs = [S.denoise(pk, model, sched, trans, diverse, x_T=x_T, us=us, timesteps=T, use_graph=g_) for g_ in (True, False, None)]
+    finally:
+        S.GraphedDenoiseStep.__init__ = orig
+    assert len(made) == 2                                    # use_graph=True and the default (256 token rows) replay
+    assert outs[0][2] == outs[1][2] == outs[2][2] and outs[0][3] == outs[1][3]
+    assert all(len(seq) == int(n) for seq, n in zip(outs[0][2], pk["ligand_attn_mask"].sum(1)))
