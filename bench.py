@@ -489,6 +489,7 @@ def main():
             import bench_single
             # BASELINE configs[0] on the GPU: ONE 64-residue pocket, 50 reverse steps (latency, not throughput)
             out["single_pocket"] = bench_single.run(seq_len=64, batch=1, steps=50)
+            out["single_pocket"]["sequence_stage"] = bench_single.run_sequence(seq_len=64, batch=1, steps=50)
             if not args.no_joint_leg:
                 # BASELINE configs[4], one GPU's share: 128 pockets x L=128, structure T=1000 -> hand-over on the device ->
                 # sequence T=50 (sequence_model/sample_by_generated_angles.py:196-278); the reference's padded frames,

@@ -58,6 +58,35 @@ def run(seq_len=64, batch=1, steps=50, graph=None, chains=3):
             "note": "structure_model/sample.py p_sample_loop: encoder + cross K/V once per chain, 12-layer decoder + DDPM update per step"}
 
 
+def run_sequence(seq_len=64, batch=1, steps=50, graph=None, chains=3):
+    """The sequence stage for ONE pocket: 50 reverse steps of the 6-layer amino-acid denoiser (sequence_model/sample.py
+    ``denoise``, BLOSUM transition, categorical draws); best of ``chains``."""
+    import contextlib
+    import io
+    from e3diff_amd.sequence_model import sample as Q
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    from e3diff_amd.sequence_model.utils import BlosumTransition, PredefinedNoiseScheduleDiscrete
+    L, B, T = seq_len, batch, steps
+    c = dict(hidden_size=768, num_attention_heads=12, intermediate_size=1024, num_hidden_layers=6, max_position_embeddings=L)
+    torch.manual_seed(0)
+    model = PeptideDiff(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("ACDEFGHIKLMNPQRSTVWY"),
+                        loss_func=torch.nn.CrossEntropyLoss(), noise_schedule="cosine", timesteps=T).eval().to(DEV)
+    sched, trans = PredefinedNoiseScheduleDiscrete("cosine", T).to(DEV), BlosumTransition(x_classes=20)
+    pk = synthetic_pockets(B, L, seed=1, with_ligand_seq=True)
+    best = None
+    for _ in range(chains + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            Q.denoise(pk, model, sched, trans, True, timesteps=T, use_graph=None if graph is None else bool(graph))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"batch": B, "seq_len": L, "timesteps": T, "arithmetic": pkg.ops.GEMM_MODE,
+            "graph_replay": "sampler default" if graph is None else bool(graph), "ms_per_chain": best * 1e3, "ms_per_step": best / T * 1e3,
+            "note": "sequence_model/sample.py denoise: 6-layer decoder + discrete posterior draw per step, host to sequences included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seq-len", type=int, default=64)
