@@ -126,7 +126,7 @@ except ImportError:      # very old torch: training.fit() bumps the generation a
 # per-device pool, handed out once per owner (a BertSelfAttention module) and only ever raised by the kernels:
 # ``reset_absmax()`` (one fill launch) zeroes them all -- models call it once per batch / sampling chain, so a slot holds
 # the running maximum of that chain.  A stale (too large) value is still a valid bound: it can only cost the skip.
-_ABSMAX_POOLS = {}      # device index -> [pool tensor, slots handed out]
+_ABSMAX_POOLS = {}      # device index -> [current pool tensor, slots handed out of it, earlier (full) pool tensors]
 ABSMAX_POOL_SLOTS = 4096
 
 
@@ -138,9 +138,10 @@ def absmax_slot(owner, name, device):
     if t is None:
         ent = _ABSMAX_POOLS.get(device.index)
         if ent is None:
-            ent = _ABSMAX_POOLS[device.index] = [torch.zeros(ABSMAX_POOL_SLOTS, device=device, dtype=torch.float32), 0]
-        if ent[1] >= ABSMAX_POOL_SLOTS:
-            raise RuntimeError("absmax pool exhausted")
+            ent = _ABSMAX_POOLS[device.index] = [torch.zeros(ABSMAX_POOL_SLOTS, device=device, dtype=torch.float32), 0, []]
+        if ent[1] >= ABSMAX_POOL_SLOTS:     # slots are never handed back (a process that builds model after model): grow
+            ent[2].append(ent[0])
+            ent[0], ent[1] = torch.zeros(ABSMAX_POOL_SLOTS, device=device, dtype=torch.float32), 0
         t = slots[key] = ent[0][ent[1]:ent[1] + 1]
         ent[1] += 1
     return t
@@ -152,6 +153,8 @@ def reset_absmax(device=None):
     ent = _ABSMAX_POOLS.get(idx)
     if ent is not None:
         ent[0].zero_()
+        for old_pool in ent[2]:
+            old_pool.zero_()
 
 
 def absmax(x, target=None):
