@@ -4,7 +4,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=../libe3d_hip.so
-SRCS="capi.hip gemm_f32.hip gemm_split.hip gemm_skinny.hip attn_relkey.hip attn_relkey_split.hip attn_relkey_coop.hip rowops.hip sampler.hip train_ops.hip attn_bwd.hip attn_bwd_split.hip attn_bwd_coop.hip nerf.hip dropout.hip optim.hip"
+SRCS="capi.hip gemm_f32.hip gemm_split.hip gemm_rowln.hip gemm_skinny.hip attn_relkey.hip attn_relkey_split.hip attn_relkey_coop.hip rowops.hip sampler.hip train_ops.hip attn_bwd.hip attn_bwd_split.hip attn_bwd_coop.hip nerf.hip dropout.hip optim.hip"
 OBJS=""
 pids=()
 for s in $SRCS; do

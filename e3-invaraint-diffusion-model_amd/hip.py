@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3D_HIP_LIB", os.path.join(_HERE, "libe3d_hip.so"))   # override: kernel experiments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = c_void_p
 _SIGNATURES = {
@@ -51,6 +51,12 @@ _SIGNATURES = {
     "e3d_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_int64]),
     "e3d_gemm_bias_act_f32_split_ln": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_float,
                                                _P, _P, c_int64, _P, _P, _P, _P]),
+    # row-complete GEMM + bias + residual + LayerNorm (ABI v4)
+    "e3d_weight_planes_bytes": (c_int64, [c_int, c_int]),
+    "e3d_weight_planes_f32_split": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "e3d_gemm_residual_layernorm_supported": (c_int, [c_int, c_int, c_int, c_int64]),
+    "e3d_gemm_residual_layernorm_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_int64,
+                                                      c_int, c_int, c_int, c_int, c_float, _P]),
     "e3d_row_stats_f32": (c_int, [_P, c_float, _P, c_int, c_int, _P]),
     "e3d_layernorm_from_stats_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "e3d_gemm_wgrad_ragged_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_uint64, c_int, c_int, c_int, _P]),

@@ -521,12 +521,61 @@ def residual_layernorm(x, residual, gamma, beta, eps, want_s=False, drop=None):
     return (out, s) if want_s else out
 
 
+# Row-complete GEMM + bias + residual + LayerNorm (csrc/gemm_rowln.hip): BertSelfOutput / BertOutput in ONE launch at large
+# M -- a workgroup owns whole 768-wide rows, the pre-norm sum never leaves its registers.  The weight goes in PRE-SPLIT
+# into its two 16-bit terms (fragment-order planes, built once per weight version by a small kernel and cached on the
+# weight like every derived-weight cache).  From ROWLN_MIN_M rows upwards (one 128-row group per CU and more; below that
+# the unfused pair's 256 x 256 / 128 x 128 tiles fill the chip better); E3D_GEMM_ROWLN=0 switches the path off (A/B runs).
+ROWLN_MIN_M = int(os.environ.get("E3D_GEMM_ROWLN_MIN_M", "32768")) if os.environ.get("E3D_GEMM_ROWLN", "1") == "1" else 1 << 62
+
+
+def weight_planes(weight, terms):
+    """(planes, out_scale): ``weight`` [N, K] split into its hi / lo 16-bit terms in MFMA-fragment order
+    (e3d_weight_planes_f32_split); for f16x3 the power-of-two-scaled copy is split and its inverse power returned."""
+    ent = getattr(weight, "_e3d_planes_w", None)
+    key = weight_key(weight) + (terms,)
+    if ent is not None and ent[0] == key:
+        return ent[1], ent[2]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("weight_planes: cache miss inside a stream capture (warm the op up before capturing)")
+    src, scale = f16_weight(weight) if terms == 19 else (weight.detach(), 1.0)
+    N, K = src.shape
+    nbytes = hip.lib().e3d_weight_planes_bytes(N, K)
+    if nbytes < 0:
+        raise ValueError(f"weight_planes: unsupported shape {tuple(src.shape)}")
+    planes = torch.empty((nbytes,), dtype=torch.uint8, device=src.device)
+    hip.check(hip.lib().e3d_weight_planes_f32_split(_p(src), N, K, terms, _p(planes), _stream()), "e3d_weight_planes_f32_split")
+    try:
+        weight._e3d_planes_w = (key, planes, scale)
+    except AttributeError:
+        pass
+    return planes, scale
+
+
+def rowln_ok(terms, M, H, K, a):
+    return (terms in (3, 19) and M >= ROWLN_MIN_M and a.stride(1) == 1
+            and bool(hip.lib().e3d_gemm_residual_layernorm_supported(M, H, K, a.stride(0))))
+
+
 def linear_residual_layernorm(a, weight, bias, residual, gamma, beta, eps, mode=None):
-    """LayerNorm(a @ weight^T + bias + residual) * gamma + beta  (BertSelfOutput / BertOutput in eval mode).  Small M: the
-    second launch of the skinny GEMM does the row finish (bit-identical to gemm + residual_layernorm); otherwise the pair."""
+    """LayerNorm(a @ weight^T + bias + residual) * gamma + beta  (BertSelfOutput / BertOutput in eval mode).  Large M: the
+    row-complete kernel (one launch, no pre-norm tensor); small M: the second launch of the skinny GEMM does the row
+    finish (bit-identical to gemm + residual_layernorm); otherwise the pair."""
     M, K = a.shape
     H = weight.shape[0]
     terms = GEMM_MODES[GEMM_MODE if mode is None else mode]
+    if rowln_ok(terms, M, H, K, a) and (residual is None or (residual.stride(1) == 1 and residual.stride(0) % 4 == 0)):
+        for t, n in ((a, "a"), (weight, "weight"), (bias, "bias"), (residual, "residual"), (gamma, "gamma"), (beta, "beta")):
+            _chk(t, "linear_residual_layernorm." + n)
+        assert weight.is_contiguous() and weight.shape[1] == K and (residual is None or residual.shape == (M, H))
+        planes, scale = weight_planes(weight, terms)
+        out = torch.empty((M, H), device=a.device, dtype=torch.float32)
+        with _timed("gemm_layernorm", (M, H, K)):
+            hip.check(hip.lib().e3d_gemm_residual_layernorm_f32_split(
+                _p(a), a.stride(0), _p(planes), _p(bias), _p(residual), residual.stride(0) if residual is not None else 0,
+                _p(gamma), _p(beta), eps, _p(out), out.stride(0), M, H, K, terms, scale, _stream()),
+                "e3d_gemm_residual_layernorm_f32_split")
+        return out
     if not (_skinny_ok(terms, M, H, K, a) and H in (256, 512, 768, 1024) and a.stride(1) == 1):
         return residual_layernorm(gemm(a, weight, bias, mode=mode), residual, gamma, beta, eps)
     for t, n in ((a, "a"), (weight, "weight"), (bias, "bias"), (residual, "residual"), (gamma, "gamma"), (beta, "beta")):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define E3D_ABI_VERSION 3
+#define E3D_ABI_VERSION 4
 
 /* ``terms`` of the split-operand entry points: how an fp32 operand enters the 16-bit matrix cores.
  *   3  (bf16x3): 2 bf16 terms, 3 cross products, ~2^-17 per product, fp32 exponent range;
@@ -418,6 +418,25 @@ int e3d_gemm_bias_act_f32_split_ln(const float* A, int64_t lda, const float* W, 
 int e3d_row_stats_f32(const float* z, float eps, float* stats, int M, int H, void* stream);
 int e3d_layernorm_from_stats_f32(const float* z, const float* stats, const float* gamma, const float* beta, float* out, int M,
                                  int H, void* stream);
+
+/* ---- row-complete GEMM + bias + residual + LayerNorm (ABI v4; inference at large M) ----------------------------------
+ * BertSelfOutput / BertOutput whole -- LayerNorm(dense(x) + residual), transformers 4.38.2 modeling_bert.py, reached through
+ * structure_model/model.py:197-213 and sequence_model/model.py:226-231 -- as ONE launch whose workgroups own whole 768-wide
+ * rows: out[M,768] = LayerNorm(A[M,K] W[768,K]^T * out_scale + bias + residual) * gamma + beta.  The pre-norm sum never
+ * leaves the accumulators (the GEMM + e3d_residual_layernorm_fwd pair writes it and reads it back: 4 row passes against 3).
+ * Same 2-term split products in the same order as e3d_gemm_bias_act_f32_split (terms 3 or 19: the pre-norm sums are
+ * bit-identical), same two-pass statistics as e3d_residual_layernorm_fwd (outputs agree to a few 1e-7).
+ *   w_planes: the weight PRE-SPLIT into its two 16-bit terms in MFMA-fragment order by e3d_weight_planes_f32_split (once
+ *     per weight version; e3d_weight_planes_bytes(N, K) = N K 4 bytes; for terms = 19 split the power-of-two-scaled weight
+ *     and pass the inverse power as out_scale, exactly as for the *_ex GEMM entry points);
+ *   residual may be NULL; A, residual and out are row-strided (lda, ldr, ldo in floats).
+ * Shapes: N = 768, M % 32 == 0, K % 32 == 0, K >= 64 (e3d_gemm_residual_layernorm_supported). */
+int64_t e3d_weight_planes_bytes(int N, int K);
+int e3d_weight_planes_f32_split(const float* W, int N, int K, int terms, void* planes, void* stream);
+int e3d_gemm_residual_layernorm_supported(int M, int N, int K, int64_t lda);
+int e3d_gemm_residual_layernorm_f32_split(const float* A, int64_t lda, const void* w_planes, const float* bias,
+                                          const float* residual, int64_t ldr, const float* gamma, const float* beta, float eps,
+                                          float* out, int64_t ldo, int M, int N, int K, int terms, float out_scale, void* stream);
 
 /* ---- optimizer step (ABI v3) ------------------------------------------------------------------------------------------
  * Global-norm gradient clip + AdamW over ALL parameters in three launches: what Lightning's gradient_clip_val = 1.0

@@ -663,3 +663,55 @@ def test_gemm_skinny_under_load_every_word(pkg, hip):
         bad += int(((got - ref).abs() > 2e-5 * ref.abs().max()).sum())
     torch.cuda.synchronize()
     assert bad == 0, bad
+
+
+# ------------------------------------------------------------------------------------- row-complete GEMM + LayerNorm
+@pytest.mark.parametrize("M,K", [(32, 768), (96, 64), (224, 1024), (4096, 768), (8192 + 160, 1024), (65536, 768)])
+@pytest.mark.parametrize("mode,tol", [("f16x3", 5e-6), ("bf16x3", 3e-5)])
+def test_gemm_rowln_matches_the_unfused_pair(pkg, hip, monkeypatch, M, K, mode, tol):
+    """BertSelfOutput / BertOutput as one row-complete launch (e3d_gemm_residual_layernorm_f32_split: LDS-DMA staging,
+    pre-split weight planes, residual through an LDS ring, LayerNorm in the accumulators) against the unfused pair it
+    replaces (<= 1e-6 of the output scale: same products in the same order, the row statistics summed in another order)
+    and against fp64; every tile form (96 / 64 / 32 rows, several tiles per workgroup), with and without a residual,
+    a row-strided A."""
+    monkeypatch.setattr(pkg.ops, "ROWLN_MIN_M", 1)
+    H = 768
+    a_full = torch.randn(M, K + 32, generator=g(M + K))
+    a = a_full[:, :K]                                      # row stride K + 32
+    w = torch.randn(H, K, generator=g(H)) / math.sqrt(K)
+    b, res = torch.randn(H, generator=g(1)), torch.randn(M, H, generator=g(2)) * 3 + 0.5
+    gamma, beta = torch.rand(H, generator=g(3)) + 0.5, torch.randn(H, generator=g(4))
+    ad, wd, bd, rd, gd, be = (t.to(DEV) for t in (a_full, w, b, res, gamma, beta))
+    ad = ad[:, :K]
+    rows = torch.randperm(M, generator=g(5))[:2048]        # fp64 check on a sample of rows (the pair check covers all)
+    for r_cpu, r_dev in ((res, rd), (None, None)):
+        fused = pkg.ops.linear_residual_layernorm(ad, wd, bd, r_dev, gd, be, 1e-12, mode=mode)
+        pair = pkg.ops.residual_layernorm(pkg.ops.gemm(ad, wd, bd, mode=mode), r_dev, gd, be, 1e-12)
+        assert torch.isfinite(fused).all()
+        assert float((fused - pair).abs().max()) <= 1e-6 * float(pair.abs().max()), float((fused - pair).abs().max())
+        pre = F.linear(a[rows].double(), w.double(), b.double()) + (0 if r_cpu is None else r_cpu[rows].double())
+        ref = F.layer_norm(pre, (H,), gamma.double(), beta.double(), 1e-12).float()
+        assert rel_err(fused[rows.to(DEV)], ref) < 4 * tol
+
+
+def test_gemm_rowln_dispatch_and_weight_updates(pkg, hip, monkeypatch):
+    """The fused path is taken from ROWLN_MIN_M rows upwards only, follows in-place weight updates (planes are keyed like
+    every derived-weight cache) and leaves the other arithmetic modes on the unfused pair."""
+    H, K, M = 768, 768, 512
+    a = torch.randn(M, K, device=DEV)
+    w = (torch.randn(H, K, device=DEV) / math.sqrt(K)).contiguous()
+    b, res = torch.randn(H, device=DEV), torch.randn(M, H, device=DEV)
+    gamma, beta = torch.rand(H, device=DEV) + 0.5, torch.randn(H, device=DEV)
+    small = pkg.ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode="f16x3")
+    assert getattr(w, "_e3d_planes_w", None) is None           # default threshold: M = 512 stays on the skinny / pair path
+    monkeypatch.setattr(pkg.ops, "ROWLN_MIN_M", 1)
+    fused = pkg.ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode="f16x3")
+    assert w._e3d_planes_w is not None and float((fused - small).abs().max()) < 2e-6 * float(small.abs().max())
+    w.mul_(0.5)
+    pkg.ops.invalidate_weight_caches()
+    again = pkg.ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode="f16x3")
+    pair = pkg.ops.residual_layernorm(pkg.ops.gemm(a, w, b, mode="f16x3"), res, gamma, beta, 1e-12)
+    assert float((again - pair).abs().max()) < 2e-6 * float(pair.abs().max())
+    for mode in ("f32", "bf16x6"):
+        got = pkg.ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode=mode)
+        assert torch.equal(got, pkg.ops.residual_layernorm(pkg.ops.gemm(a, w, b, mode=mode), res, gamma, beta, 1e-12))
