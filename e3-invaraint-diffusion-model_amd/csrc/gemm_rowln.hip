@@ -94,6 +94,21 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
 #ifndef ROWLN_LAB
 #define ROWLN_LAB 0
 #endif
+#ifdef ROWLN_STAMPS   // lab builds only (tools/lab/rowln_stamps.py): s_memtime stamps of waves 0 and 4 of one workgroup
+__device__ long long rowln_stamps[2][64][8];
+__device__ long long rowln_tile_stamps[2][8][8];
+#define RSTAMP(step, slot)                                                                                        \
+    do {                                                                                                          \
+        if (stamp_on && (step) < 64 && lane == 0) rowln_stamps[wid >> 2][(step)][(slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define TSTAMP(slot)                                                                                              \
+    do {                                                                                                          \
+        if (stamp_on && tile_no < 8 && lane == 0) rowln_tile_stamps[wid >> 2][tile_no][(slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define RSTAMP(step, slot) do {} while (0)
+#define TSTAMP(slot) do {} while (0)
+#endif
 #define E3D_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // raw barrier (a __syncthreads() would drain every LDS-DMA in flight), fenced for the COMPILER on both sides
 #define E3D_BARRIER()                          \
@@ -208,6 +223,10 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
     issue_w(0, 0);
     issue_w(1, 1);
     int next_row0 = 0, next_rows = 0;
+#ifdef ROWLN_STAMPS
+    const bool stamp_on = blockIdx.x == 77 && (wid & 3) == 0;
+    int tile_no = 0;
+#endif
 
     // One tile of NM m-blocks (32 NM rows): the whole body is instantiated per NM so that no accumulator ever meets a
     // control-flow merge (hipcc answers those with copies of 16-register tuples, i.e. with spills at this register count).
@@ -223,13 +242,17 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+        TSTAMP(0);
         E3D_VMCNT(0);      // W step 0 and A pair 0 (issued at kernel entry / under the previous tile's epilogue) + its stores
         E3D_BARRIER();
+        TSTAMP(1);
 
         // One k16 step.  The W planes of a step are PRIVATE to the wave that reads them (wave w loads and reads pieces
         // 6 w .. 6 w + 5 = its own three column blocks), so a W buffer is refilled -- with the step after next -- as soon as
         // this wave's B fragments sit in registers: no barrier is involved, and a W piece has almost two steps to arrive.
-        auto compute = [&](int ks, int abuf, int w_next) {
+        auto compute = [&](int ks, int abuf, int w_next, auto with_a, const float* a_src, int a_pair, int stamp_step) {
+            RSTAMP(stamp_step, 0);
+            constexpr bool WITH_A = decltype(with_a)::value;      // this step also fetches an A pair (2 more pieces)
             const unsigned char* ab = smem + abuf * A_PAIR;
             const unsigned char* wb = smem + ks * W_STEP + b_roff;
             X8 bh[3], bl[3];
@@ -240,8 +263,25 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
             }
             f32x4 x0 = *reinterpret_cast<const f32x4*>(ab + (a_roff ^ (64 * ks)));
             f32x4 x1 = *reinterpret_cast<const f32x4*>(ab + (a_roff ^ (64 * ks + 16)));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the buffer is free
-            if (!(ROWLN_LAB & 4)) issue_w(w_next, ks);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the W buffer is free
+            RSTAMP(stamp_step, 1);
+            // The step's DMA pieces (6 of W, 2 of A) are issued ONE AT A TIME between the MFMA triplets: eight waves that
+            // issue their pieces together queue behind the CU's one address unit (~16 cycles per piece, 56 pieces per step)
+            // and none of them issues an MFMA meanwhile -- measured: the k loop then costs MFMA time PLUS DMA time.
+            const unsigned char* gw = Wp + (int64_t)w_next * W_STEP + w_lane;
+            unsigned char* lw = smem + ks * W_STEP + wid * 6144;
+            const unsigned char* ga = reinterpret_cast<const unsigned char*>(a_src + a_pair * 32);
+            unsigned char* la = smem + LDS_A + (abuf ^ 1) * A_PAIR + wid * 1024;
+            auto piece = [&](auto idx) {
+                constexpr int I = decltype(idx)::value;
+                if constexpr (I < 6) {
+                    if (ROWLN_LAB & 4) return;
+                    if constexpr (I < 4) glds16<I * 1024>(gw, lw);
+                    else glds16<(I - 4) * 1024>(gw + 4096, lw + 4096);
+                } else if constexpr (I < 8) {
+                    if constexpr (WITH_A) glds16<0>(ga + a_lane[I - 6], la + (I - 6) * 8192);
+                }
+            };
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 X8 ah, al;
@@ -259,8 +299,25 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                         acc[m][n] = mma16(al, bh[n], acc[m][n]);
                         acc[m][n] = mma16(ah, bh[n], acc[m][n]);
                     }
+                    // NM * 3 slots for 8 pieces: NM = 3 one per triplet, NM = 2 pieces 6, 7 ride on the last slots, NM = 1 three each
+                    constexpr int SLOTS = NM * 3, PER = (8 + SLOTS - 1) / SLOTS;
+                    const int slot = m * 3 + n;
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) {
+                        const int i = slot * PER + j;
+                        if (i == 0) piece(std::integral_constant<int, 0>{});
+                        if (i == 1) piece(std::integral_constant<int, 1>{});
+                        if (i == 2) piece(std::integral_constant<int, 2>{});
+                        if (i == 3) piece(std::integral_constant<int, 3>{});
+                        if (i == 4) piece(std::integral_constant<int, 4>{});
+                        if (i == 5) piece(std::integral_constant<int, 5>{});
+                        if (i == 6) piece(std::integral_constant<int, 6>{});
+                        if (i == 7) piece(std::integral_constant<int, 7>{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // keep every piece behind its triplet
                 }
             }
+            RSTAMP(stamp_step, 2);
         };
 
         // Branch-free k loop, ONE barrier per k32 pair (it orders the shared A buffers only).  Even step 2p: A pair p+1 ->
@@ -269,17 +326,20 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         // nobody reads any more, so every iteration issues and waits for the same counts.
         for (int p = 0; p < npairs; ++p) {
             const int abuf = p & 1;
-            issue_a(a_tile, (ROWLN_LAB & 2) ? 0 : min(p + 1, npairs - 1), abuf ^ 1);
-            compute(0, abuf, min(2 * p + 2, last_step));
+            compute(0, abuf, min(2 * p + 2, last_step), std::true_type{}, a_tile, (ROWLN_LAB & 2) ? 0 : min(p + 1, npairs - 1), 2 * p);
             if (ROWLN_LAB & 4) E3D_VMCNT(2);
             else E3D_VMCNT(8);     // W(2p+1) has landed (issued a step ago); A(p+1) and W(2p+2) may still fly
-            compute(1, abuf, min(2 * p + 3, last_step));
+            RSTAMP(2 * p, 3);
+            compute(1, abuf, min(2 * p + 3, last_step), std::false_type{}, a_tile, 0, 2 * p + 1);
             if (ROWLN_LAB & 4) E3D_VMCNT(0);
             else E3D_VMCNT(6);     // A(p+1) and W(2p+2) have landed; W(2p+3) may still fly
+            RSTAMP(2 * p + 1, 3);
             E3D_BARRIER();
+            RSTAMP(2 * p + 1, 4);
         }
         E3D_VMCNT(0);              // the two re-fetched W steps of the tail
         E3D_BARRIER();
+        TSTAMP(2);
 
         // ------------------------------------------------------------------ epilogue
         // z = fma(acc, out_scale, bias) + residual, exactly as the unfused pair forms it
@@ -325,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
             }
         }
         E3D_LDS_BARRIER();     // every wave is past its last read of the W / A buffers and of the ring
+        TSTAMP(3);
 
         // the next tile's first loads fly under the LayerNorm arithmetic and the stores
         next_row0 = row0 + 32 * NM;
@@ -431,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
             if (SINGLE) tu = reduce16(u);
             exchange(tv, tu, true);     // (its first barrier also orders every lane's mean reads before the table is rewritten)
         }
+        TSTAMP(4);
         float gv[3], bt[3];
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
@@ -448,6 +510,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
 #pragma unroll
                     for (int n = 0; n < 3; ++n) o[(int64_t)j * ldo + 32 * n] = fmaf(acc[m][n][4 * q + j] * rstd[j], gv[n], bt[n]);
             }
+        TSTAMP(5);
+#ifdef ROWLN_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP(6);
+        ++tile_no;
+#endif
         if (more) E3D_LDS_BARRIER();     // the row constants are read before the next tile's epilogue can rewrite them
         return more;
     };
@@ -481,6 +549,14 @@ int launch_rowln(const float* A, int64_t lda, const void* Wp, const float* bias,
 }
 
 }  // namespace
+
+#ifdef ROWLN_STAMPS
+extern "C" int e3d_debug_rowln_stamps(long long* steps, long long* tiles) {
+    int rc = (int)hipMemcpyFromSymbol(steps, HIP_SYMBOL(rowln_stamps), sizeof(long long) * 2 * 64 * 8);
+    if (rc) return rc;
+    return (int)hipMemcpyFromSymbol(tiles, HIP_SYMBOL(rowln_tile_stamps), sizeof(long long) * 2 * 8 * 8);
+}
+#endif
 
 extern "C" int64_t e3d_weight_planes_bytes(int N, int K) { return (N % 32 || K % 16 || N <= 0 || K <= 0) ? -1 : (int64_t)N * K * 4; }
 
