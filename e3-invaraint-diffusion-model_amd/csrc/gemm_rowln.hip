@@ -17,8 +17,9 @@
 //   * A stays fp32 in memory; a k32 pair of the tile's rows (128 B per row: whole cache lines) is copied into an image of
 //     128-byte rows whose 16-byte chunks are XOR-ed by (row >> 1) & 7 on the SOURCE side (conflict-free ds_read_b128 of
 //     fragment rows), and every wave splits the A fragments in registers right before its MFMAs.
-// Two W buffers (k16 steps, wave-private: refilled two steps ahead without a barrier) + two A buffers (k32 pairs) = 128 KB;
-// counted vmcnt waits and ONE raw s_barrier per k32 pair.
+// Two W buffers (k16 steps, wave-private: refilled two steps ahead without a barrier) + three A buffers (k32 pairs) = 144 KB;
+// the k loop is software-pipelined (the next step's fragments are read under this step's MFMAs into a second register
+// set); counted vmcnt waits and ONE raw s_barrier per k32 pair.
 // Epilogue: the residual tile streams through a three-buffer LDS ring of 16-row chunks (coalesced 1-KB DMA pieces, never a
 // per-lane epilogue load); row sums meet through a transposing shuffle butterfly per half wave and a 3-KB LDS exchange.
 #include <type_traits>
@@ -42,11 +43,11 @@ __device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x
 constexpr int RN = 768, RBM = 96, NBLK = RN / 32;
 constexpr int W_STEP = NBLK * 2 * 1024;          // bytes of one k16 step of the weight planes (49152)
 constexpr int A_PAIR = 128 * 128;                // one k32 pair of the A tile: 16 DMA pieces of 8 fp32 rows x 128 B (12 used)
-constexpr int LDS_A = 2 * W_STEP;                // A buffers behind the two W buffers
+constexpr int LDS_A = 2 * W_STEP;                // three A buffers behind the two W buffers (96 + 48 = 144 KB)
 constexpr int RES_CHUNK = 16 * RN * 4;           // residual ring: 16 rows per chunk (49152)
 constexpr int LDS_STATS = 3 * RES_CHUNK;         // [8][96] partial sums + [96] row constants, behind everything else
 constexpr int LDS_COLS = LDS_STATS + (8 * RBM + RBM) * 4;   // bias | gamma | beta, 3 x 768 floats
-constexpr int LDS_TOTAL = LDS_COLS + 3 * RN * 4;            // 160128 of the CU's 163840 (k loop: LDS_A + 2 A_PAIR = 131072)
+constexpr int LDS_TOTAL = LDS_COLS + 3 * RN * 4;            // 160128 of the CU's 163840 (k loop: LDS_A + 3 A_PAIR = 147456)
 
 // the two 16-bit terms of 8 consecutive fp32 values, exactly as gemm_split.hip's split4<2, E> forms them
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, f16x8& hi, f16x8& lo) {
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(const float* __restr
 #ifdef ROWLN_STAMPS   // lab builds only (tools/lab/rowln_stamps.py): s_memtime stamps of waves 0 and 4 of one workgroup
 __device__ long long rowln_stamps[2][64][8];
 __device__ long long rowln_tile_stamps[2][8][8];
+__device__ long long rowln_wg_times[512][4];     // per workgroup: s_memrealtime (100 MHz) and s_memtime at entry / exit
 #define RSTAMP(step, slot)                                                                                        \
     do {                                                                                                          \
         if (stamp_on && (step) < 64 && lane == 0) rowln_stamps[wid >> 2][(step)][(slot)] = __builtin_readcyclecounter(); \
@@ -134,8 +136,18 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 }
 
 // rows of the next tile of a workgroup that has ``left`` rows to go (multiples of 32): 96 while at least 160 remain (or
-// exactly 96), otherwise the rest in halves no larger than 96 (256 -> 96, 96, 64; 128 -> 64, 64; 224 -> 96, 64, 64)
-__device__ __forceinline__ int next_tile_rows(int left) {
+// exactly 96), otherwise the rest in halves no larger than 96 (256 -> 96, 96, 64; 128 -> 64, 64; 224 -> 96, 64, 64).
+// ``pattern`` (workgroup-dependent, 0..3) permutes the order for a 256-row group -- 96 96 64 / 64 96 96 / 96 64 96 /
+// 64 64 64 64 -- so that neighbouring workgroups reach their epilogues (residual read + output store: HBM-bound, the matrix
+// pipe idle) at different times instead of all CUs hammering HBM together and all running MFMAs together.
+__device__ __forceinline__ int next_tile_rows(int left, int pattern, int group_rows) {
+#ifndef ROWLN_NO_PATTERNS
+    if (group_rows == 256) {
+        if (pattern == 1 && left == 256) return 64;
+        if (pattern == 2 && left == 160) return 64;
+        if (pattern == 3) return 64;
+    }
+#endif
     if (left >= 160 || left == 96) return 96;
     if (left > 96) return 64;
     return left;
@@ -217,15 +229,21 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
     const bool bit16 = (lane & 16) != 0, bit8 = (lane & 8) != 0, bit4 = (lane & 4) != 0, bit2 = (lane & 2) != 0,
                bit1 = (lane & 1) != 0;
 
-    int rows = next_tile_rows(row_end - row0);
+    const int pattern = (blockIdx.x >> 3) & 3, group_rows = row_end - row0;
+    int rows = next_tile_rows(row_end - row0, pattern, group_rows);
     a_offsets(rows);
     issue_a(A + (int64_t)row0 * lda, 0, 0);
     issue_w(0, 0);
     issue_w(1, 1);
+    issue_a(A + (int64_t)row0 * lda, 1, 1);
     int next_row0 = 0, next_rows = 0;
 #ifdef ROWLN_STAMPS
     const bool stamp_on = blockIdx.x == 77 && (wid & 3) == 0;
     int tile_no = 0;
+    if (tid == 0 && blockIdx.x < 512) {
+        rowln_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+        rowln_wg_times[blockIdx.x][1] = __builtin_readcyclecounter();
+    }
 #endif
 
     // One tile of NM m-blocks (32 NM rows): the whole body is instantiated per NM so that no accumulator ever meets a
@@ -243,52 +261,43 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
         TSTAMP(0);
-        E3D_VMCNT(0);      // W step 0 and A pair 0 (issued at kernel entry / under the previous tile's epilogue) + its stores
+        // Software-pipelined k loop.  At the top of step s the wave already holds the step's B fragments (register set s & 1)
+        // and the raw A fragment of its first row block: they were read while step s - 1 computed.  So the step opens with
+        // MFMAs, W buffer s & 1 is free at once (the wave's own reads of it are a step old: W(s+2) goes in straight away,
+        // two full steps ahead), and one third into the step -- behind the first row block's nine MFMAs -- the wave waits for
+        // W(s+1) (issued a step ago), reads the next step's fragments into the other register set and carries on.
+        // A pairs live in THREE buffers: the workgroup's one barrier per pair sits in the middle of the odd step, after it
+        // pair p+1 is visible to everybody (first read: the fragment prefetch that follows) and pair p+2 may be fetched into
+        // the buffer pair p-1 was read from (every wave has finished step 2p by then).
+        int a_cur = 0, a_nxt = A_PAIR, a_nx2 = 2 * A_PAIR;      // byte offsets of the three A buffers from LDS_A (a_roff carries LDS_A)
+        E3D_VMCNT(8);      // A(0) and W(0) have landed (W(1) and A(1), issued after them, may still fly)
         E3D_BARRIER();
         TSTAMP(1);
-
-        // One k16 step.  The W planes of a step are PRIVATE to the wave that reads them (wave w loads and reads pieces
-        // 6 w .. 6 w + 5 = its own three column blocks), so a W buffer is refilled -- with the step after next -- as soon as
-        // this wave's B fragments sit in registers: no barrier is involved, and a W piece has almost two steps to arrive.
-        auto compute = [&](int ks, int abuf, int w_next, auto with_a, const float* a_src, int a_pair, int stamp_step) {
-            RSTAMP(stamp_step, 0);
-            constexpr bool WITH_A = decltype(with_a)::value;      // this step also fetches an A pair (2 more pieces)
-            const unsigned char* ab = smem + abuf * A_PAIR;
-            const unsigned char* wb = smem + ks * W_STEP + b_roff;
-            X8 bh[3], bl[3];
+        X8 bh0[3], bl0[3], bh1[3], bl1[3];
+        f32x4 x0, x1;
 #pragma unroll
-            for (int n = 0; n < 3; ++n) {
-                bh[n] = *reinterpret_cast<const X8*>(wb + n * 2048);
-                bl[n] = *reinterpret_cast<const X8*>(wb + n * 2048 + 1024);
-            }
-            f32x4 x0 = *reinterpret_cast<const f32x4*>(ab + (a_roff ^ (64 * ks)));
-            f32x4 x1 = *reinterpret_cast<const f32x4*>(ab + (a_roff ^ (64 * ks + 16)));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the W buffer is free
-            RSTAMP(stamp_step, 1);
-            // The step's DMA pieces (6 of W, 2 of A) are issued ONE AT A TIME between the MFMA triplets: eight waves that
-            // issue their pieces together queue behind the CU's one address unit (~16 cycles per piece, 56 pieces per step)
-            // and none of them issues an MFMA meanwhile -- measured: the k loop then costs MFMA time PLUS DMA time.
+        for (int n = 0; n < 3; ++n) {
+            bh0[n] = *reinterpret_cast<const X8*>(smem + b_roff + n * 2048);
+            bl0[n] = *reinterpret_cast<const X8*>(smem + b_roff + n * 2048 + 1024);
+        }
+        x0 = *reinterpret_cast<const f32x4*>(smem + a_cur + a_roff);
+        x1 = *reinterpret_cast<const f32x4*>(smem + a_cur + (a_roff ^ 16));
+
+        // step of parity KS (compile time): fragments in (bh, bl); the next step's go to (nh, nl)
+        auto step = [&](auto ks_c, X8 (&bh)[3], X8 (&bl)[3], X8 (&nh)[3], X8 (&nl)[3], int w_next, int a_pair_next, int stamp_step) {
+            constexpr int KS = decltype(ks_c)::value;
+            RSTAMP(stamp_step, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the reads of W buffer KS are a step old)
             const unsigned char* gw = Wp + (int64_t)w_next * W_STEP + w_lane;
-            unsigned char* lw = smem + ks * W_STEP + wid * 6144;
-            const unsigned char* ga = reinterpret_cast<const unsigned char*>(a_src + a_pair * 32);
-            unsigned char* la = smem + LDS_A + (abuf ^ 1) * A_PAIR + wid * 1024;
-            auto piece = [&](auto idx) {
-                constexpr int I = decltype(idx)::value;
-                if constexpr (I < 6) {
-                    if (ROWLN_LAB & 4) return;
-                    if constexpr (I < 4) glds16<I * 1024>(gw, lw);
-                    else glds16<(I - 4) * 1024>(gw + 4096, lw + 4096);
-                } else if constexpr (I < 8) {
-                    if constexpr (WITH_A) glds16<0>(ga + a_lane[I - 6], la + (I - 6) * 8192);
-                }
-            };
+            unsigned char* lw = smem + KS * W_STEP + wid * 6144;
+            f32x4 y0 = x0, y1 = x1;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 X8 ah, al;
                 split8(x0, x1, ah, al);
                 if (m + 1 < NM) {       // the next row block's fragment flies under this block's nine MFMAs
-                    x0 = *reinterpret_cast<const f32x4*>(ab + ((a_roff ^ (64 * ks)) + (m + 1) * 4096));
-                    x1 = *reinterpret_cast<const f32x4*>(ab + ((a_roff ^ (64 * ks + 16)) + (m + 1) * 4096));
+                    x0 = *reinterpret_cast<const f32x4*>(smem + a_cur + ((a_roff ^ (64 * KS)) + (m + 1) * 4096));
+                    x1 = *reinterpret_cast<const f32x4*>(smem + a_cur + ((a_roff ^ (64 * KS + 16)) + (m + 1) * 4096));
                 }
 #pragma unroll
                 for (int n = 0; n < 3; ++n) {     // smallest terms first (the order of gemm_split.hip: bit-identical sums)
@@ -299,46 +308,53 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                         acc[m][n] = mma16(al, bh[n], acc[m][n]);
                         acc[m][n] = mma16(ah, bh[n], acc[m][n]);
                     }
-                    // NM * 3 slots for 8 pieces: NM = 3 one per triplet, NM = 2 pieces 6, 7 ride on the last slots, NM = 1 three each
-                    constexpr int SLOTS = NM * 3, PER = (8 + SLOTS - 1) / SLOTS;
-                    const int slot = m * 3 + n;
-#pragma unroll
-                    for (int j = 0; j < PER; ++j) {
-                        const int i = slot * PER + j;
-                        if (i == 0) piece(std::integral_constant<int, 0>{});
-                        if (i == 1) piece(std::integral_constant<int, 1>{});
-                        if (i == 2) piece(std::integral_constant<int, 2>{});
-                        if (i == 3) piece(std::integral_constant<int, 3>{});
-                        if (i == 4) piece(std::integral_constant<int, 4>{});
-                        if (i == 5) piece(std::integral_constant<int, 5>{});
-                        if (i == 6) piece(std::integral_constant<int, 6>{});
-                        if (i == 7) piece(std::integral_constant<int, 7>{});
+                    if (m == 0) {       // the six W pieces of step s + 2, two behind each triplet of the first row block
+                        if (n == 0) { glds16<0>(gw, lw); glds16<1024>(gw, lw); }
+                        if (n == 1) { glds16<2048>(gw, lw); glds16<3072>(gw, lw); }
+                        if (n == 2) { glds16<0>(gw + 4096, lw + 4096); glds16<1024>(gw + 4096, lw + 4096); }
                     }
-                    __builtin_amdgcn_sched_barrier(0);     // keep every piece behind its triplet
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (m == 0) {
+                    RSTAMP(stamp_step, 1);
+                    if (KS == 1) {
+                        E3D_VMCNT(12);     // A(p+1) has landed (issued a pair ago; W(2p+2), W(2p+3) behind it may fly)
+                        E3D_BARRIER();
+                        RSTAMP(stamp_step, 4);
+                        const unsigned char* ga = reinterpret_cast<const unsigned char*>(a_tile + a_pair_next * 32);
+                        unsigned char* la = smem + LDS_A + a_nx2 + wid * 1024;
+                        glds16<0>(ga + a_lane[0], la);
+                        glds16<0>(ga + a_lane[1], la + 8192);
+                    }
+                    E3D_VMCNT(8);          // W(s+1) has landed (issued a step ago); the 6 + 2 pieces behind it may fly
+                    RSTAMP(stamp_step, 3);
+                    const unsigned char* wn = smem + (KS ^ 1) * W_STEP + b_roff;
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) {
+                        nh[n] = *reinterpret_cast<const X8*>(wn + n * 2048);
+                        nl[n] = *reinterpret_cast<const X8*>(wn + n * 2048 + 1024);
+                    }
+                    const int an = KS == 0 ? a_cur : a_nxt;       // step s + 1: same pair (k16 half 1) / next pair (half 0)
+                    y0 = *reinterpret_cast<const f32x4*>(smem + an + (a_roff ^ (64 * (KS ^ 1))));
+                    y1 = *reinterpret_cast<const f32x4*>(smem + an + (a_roff ^ (64 * (KS ^ 1) + 16)));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            x0 = y0;
+            x1 = y1;
             RSTAMP(stamp_step, 2);
         };
 
-        // Branch-free k loop, ONE barrier per k32 pair (it orders the shared A buffers only).  Even step 2p: A pair p+1 ->
-        // the other A buffer (read in pair p-1, i.e. before the last barrier), W(2p+2) -> buffer 0 once its fragments are
-        // read; odd step 2p+1: W(2p+3) -> buffer 1.  Past the end the last step / pair is fetched again into a buffer
-        // nobody reads any more, so every iteration issues and waits for the same counts.
         for (int p = 0; p < npairs; ++p) {
-            const int abuf = p & 1;
-            compute(0, abuf, min(2 * p + 2, last_step), std::true_type{}, a_tile, (ROWLN_LAB & 2) ? 0 : min(p + 1, npairs - 1), 2 * p);
-            if (ROWLN_LAB & 4) E3D_VMCNT(2);
-            else E3D_VMCNT(8);     // W(2p+1) has landed (issued a step ago); A(p+1) and W(2p+2) may still fly
-            RSTAMP(2 * p, 3);
-            compute(1, abuf, min(2 * p + 3, last_step), std::false_type{}, a_tile, 0, 2 * p + 1);
-            if (ROWLN_LAB & 4) E3D_VMCNT(0);
-            else E3D_VMCNT(6);     // A(p+1) and W(2p+2) have landed; W(2p+3) may still fly
-            RSTAMP(2 * p + 1, 3);
-            E3D_BARRIER();
-            RSTAMP(2 * p + 1, 4);
+            step(std::integral_constant<int, 0>{}, bh0, bl0, bh1, bl1, min(2 * p + 2, last_step), 0, 2 * p);
+            step(std::integral_constant<int, 1>{}, bh1, bl1, bh0, bl0, min(2 * p + 3, last_step), min(p + 2, npairs - 1), 2 * p + 1);
+            const int t = a_cur;
+            a_cur = a_nxt;
+            a_nxt = a_nx2;
+            a_nx2 = t;
         }
-        E3D_VMCNT(0);              // the two re-fetched W steps of the tail
-        E3D_BARRIER();
+        E3D_VMCNT(0);              // the re-fetched W steps / A pairs of the tail
+        E3D_LDS_BARRIER();
         TSTAMP(2);
 
         // ------------------------------------------------------------------ epilogue
@@ -391,11 +407,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         next_row0 = row0 + 32 * NM;
         const bool more = next_row0 < row_end;
         if (more) {
-            next_rows = next_tile_rows(row_end - next_row0);
+            next_rows = next_tile_rows(row_end - next_row0, pattern, group_rows);
             a_offsets(next_rows);
             issue_a(A + (int64_t)next_row0 * lda, 0, 0);
             issue_w(0, 0);
             issue_w(1, 1);
+            issue_a(A + (int64_t)next_row0 * lda, 1, 1);
         }
 
         if (ROWLN_LAB & 16) {
@@ -530,6 +547,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         rows = next_rows;
     }
     E3D_VMCNT(0);
+#ifdef ROWLN_STAMPS
+    if (tid == 0 && blockIdx.x < 512) {
+        rowln_wg_times[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+        rowln_wg_times[blockIdx.x][3] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 template <typename E>
@@ -555,6 +578,9 @@ extern "C" int e3d_debug_rowln_stamps(long long* steps, long long* tiles) {
     int rc = (int)hipMemcpyFromSymbol(steps, HIP_SYMBOL(rowln_stamps), sizeof(long long) * 2 * 64 * 8);
     if (rc) return rc;
     return (int)hipMemcpyFromSymbol(tiles, HIP_SYMBOL(rowln_tile_stamps), sizeof(long long) * 2 * 8 * 8);
+}
+extern "C" int e3d_debug_rowln_wg_times(long long* t) {
+    return (int)hipMemcpyFromSymbol(t, HIP_SYMBOL(rowln_wg_times), sizeof(long long) * 512 * 4);
 }
 #endif
 

@@ -25,6 +25,20 @@ torch.cuda.synchronize()
 steps = (ctypes.c_longlong * (2 * 64 * 8))(); tiles = (ctypes.c_longlong * (2 * 8 * 8))()
 h.e3d_debug_rowln_stamps.argtypes = [P, P]
 assert h.e3d_debug_rowln_stamps(steps, tiles) == 0
+wg = (ctypes.c_longlong * (512 * 4))()
+h.e3d_debug_rowln_wg_times.argtypes = [P]
+assert h.e3d_debug_rowln_wg_times(wg) == 0
+t0 = min(wg[4 * i] for i in range(256))
+starts = sorted((wg[4 * i] - t0) / 100.0 for i in range(256))
+ends = sorted((wg[4 * i + 2] - t0) / 100.0 for i in range(256))
+durs = sorted((wg[4 * i + 2] - wg[4 * i]) / 100.0 for i in range(256))
+clk = sorted((wg[4 * i + 3] - wg[4 * i + 1]) / max(1, wg[4 * i + 2] - wg[4 * i]) * 100 for i in range(256))
+print(f"workgroups (us, s_memrealtime): start min/med/max {starts[0]:.1f}/{starts[128]:.1f}/{starts[-1]:.1f}  end min/med/max {ends[0]:.1f}/{ends[128]:.1f}/{ends[-1]:.1f}  "
+      f"duration min/med/max {durs[0]:.1f}/{durs[128]:.1f}/{durs[-1]:.1f}  clock MHz min/med/max {clk[0]:.0f}/{clk[128]:.0f}/{clk[-1]:.0f}")
+byx = [[] for _ in range(8)]
+for i in range(256):
+    byx[i % 8].append((wg[4 * i + 2] - wg[4 * i]) / 100.0)
+print("duration by blockIdx % 8 (median us): " + " ".join(f"{sorted(v)[len(v) // 2]:.1f}" for v in byx))
 # the step stamps hold the LAST tile of the workgroup that wrote them (64 rows: NM = 2): print tile-level first
 names = ["tile top", "loads landed + barrier", "k loop done", "residual done", "stats done", "stores issued", "stores retired"]
 for g in range(2):
