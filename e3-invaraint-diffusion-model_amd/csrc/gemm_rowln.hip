@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (published by the first tile's opening barrier)
     constexpr float inv_n = 1.0f / RN;
-    const bool bit16 = (lane & 16) != 0, bit8 = (lane & 8) != 0, bit4 = (lane & 4) != 0, bit2 = (lane & 2) != 0,
+    const bool bit8 = (lane & 8) != 0, bit4 = (lane & 4) != 0, bit2 = (lane & 2) != 0,
                bit1 = (lane & 1) != 0;
 
     const int pattern = (blockIdx.x >> 3) & 3, group_rows = row_end - row0;
@@ -428,33 +428,41 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         // 16 m + register) take 16 + 8 + 4 + 2 + 1 exchanges and leave lane l with the total of index l; the 16 sums of a
         // single m-block are first added across lanes l, l ^ 16 and then halved the same way: lanes l and l ^ 16 both end
         // with the total of index l & 15.
-        auto xchg = [&](float& a, float& b, bool up, int d) {     // a <- (up ? b : a) + the partner's (up ? b : a)
-            const float send = up ? a : b, keep = up ? b : a;
-            a = keep + __shfl_xor(send, d, 64);
+        // Level 16 (lanes l <-> l ^ 16, rows of 16 lanes): v_permlane16_swap exchanges row 1 of its first operand with row 0
+        // of its second (rows 3 / 2 in the upper half wave), so swap(lo, hi) then lo + hi leaves the row-0 lanes with the
+        // lo index summed over both rows and the row-1 lanes with the hi index.  Levels 8 .. 1 stay inside a row: DPP
+        // row_mirror (l <-> 15 - l: partners differ in bit 3), row_half_mirror (7 - l: bit 2), quad_perm xor 2 / xor 1 --
+        // no LDS round trips (the ds_bpermute form of this butterfly cost ~5 k cycles per pass in waits).
+        auto swap16_sum = [&](float lo, float hi) -> float {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+            return __uint_as_float(r[0]) + __uint_as_float(r[1]);
         };
-        auto reduce32 = [&](float (&v)[32]) -> float {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xchg(v[j], v[j + 16], bit16, 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xchg(v[j], v[j + 8], bit8, 8);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xchg(v[j], v[j + 4], bit4, 4);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) xchg(v[j], v[j + 2], bit2, 2);
-            xchg(v[0], v[1], bit1, 1);
-            return v[0];
+        auto dpp_xchg = [&](float lo, float hi, bool up, auto ctrl_c) -> float {     // (up ? hi : lo) + the partner's
+            constexpr int CTRL = decltype(ctrl_c)::value;
+            const float send = up ? lo : hi, keep = up ? hi : lo;
+            return keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), CTRL, 0xF, 0xF, true));
         };
-        auto reduce16 = [&](float (&u)[16]) -> float {
+        constexpr int ROW_MIRROR = 0x140, ROW_HALF_MIRROR = 0x141, QUAD_XOR2 = 0x4E, QUAD_XOR1 = 0xB1;
+        auto reduce_in_row = [&](float (&w)[16]) -> float {      // 16 values per lane -> lane l: total of index l & 15 over its row
 #pragma unroll
-            for (int j = 0; j < 16; ++j) u[j] += __shfl_xor(u[j], 16, 64);
+            for (int j = 0; j < 8; ++j) w[j] = dpp_xchg(w[j], w[j + 8], bit8, std::integral_constant<int, ROW_MIRROR>{});
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xchg(u[j], u[j + 8], bit8, 8);
+            for (int j = 0; j < 4; ++j) w[j] = dpp_xchg(w[j], w[j + 4], bit4, std::integral_constant<int, ROW_HALF_MIRROR>{});
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xchg(u[j], u[j + 4], bit4, 4);
+            for (int j = 0; j < 2; ++j) w[j] = dpp_xchg(w[j], w[j + 2], bit2, std::integral_constant<int, QUAD_XOR2>{});
+            return dpp_xchg(w[0], w[1], bit1, std::integral_constant<int, QUAD_XOR1>{});
+        };
+        auto reduce32 = [&](float (&v)[32]) -> float {           // lane l ends with the total of index l (over its half wave)
+            float w[16];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xchg(u[j], u[j + 2], bit2, 2);
-            xchg(u[0], u[1], bit1, 1);
-            return u[0];
+            for (int j = 0; j < 16; ++j) w[j] = swap16_sum(v[j], v[j + 16]);
+            return reduce_in_row(w);
+        };
+        auto reduce16 = [&](float (&u)[16]) -> float {           // lanes l, l ^ 16 both end with the total of index l & 15
+            float w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = swap16_sum(u[j], u[j]);
+            return reduce_in_row(w);
         };
         constexpr bool PAIR = NM >= 2, SINGLE = NM != 2;       // a pair of m-blocks (0, 1) and / or a single one (NM - 1)
         constexpr int MS = NM - 1;
