@@ -283,12 +283,21 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         x0 = *reinterpret_cast<const f32x4*>(smem + a_cur + a_roff);
         x1 = *reinterpret_cast<const f32x4*>(smem + a_cur + (a_roff ^ 16));
 
+        const bool res_on = res != nullptr && !(ROWLN_LAB & 1);
+        const unsigned char* res_tile = reinterpret_cast<const unsigned char*>(res + (int64_t)row0 * ldr);
+        const int64_t res_chunk_stride = 16 * ldr * 4;
         // step of parity KS (compile time): fragments in (bh, bl); the next step's go to (nh, nl)
-        auto step = [&](auto ks_c, X8 (&bh)[3], X8 (&bl)[3], X8 (&nh)[3], X8 (&nl)[3], int w_next, int a_pair_next, int stamp_step) {
+        auto step = [&](auto ks_c, X8 (&bh)[3], X8 (&bl)[3], X8 (&nh)[3], X8 (&nl)[3], int w_next, int a_pair_next, int tail_chunk, int stamp_step) {
             constexpr int KS = decltype(ks_c)::value;
             RSTAMP(stamp_step, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the reads of W buffer KS are a step old)
-            const unsigned char* gw = Wp + (int64_t)w_next * W_STEP + w_lane;
+            // the six pieces this step sends to W buffer KS: step s + 2 of the weight -- or, in a tile's last two steps (no
+            // such step: tail_chunk = 0 / 1), the first two 16-row chunks of the RESIDUAL, whose ring buffers 0 / 1 are these
+            // very regions (a chunk's pieces 6 w .. 6 w + 5 = thirds of its rows 2 w, 2 w + 1): the epilogue finds them landed
+            const bool tail = tail_chunk >= 0;
+            const unsigned char* gbase = tail ? res_tile + tail_chunk * res_chunk_stride : Wp + (int64_t)w_next * W_STEP;
+            const unsigned char* g0 = gbase + (tail ? r_lane[0] : w_lane);
+            const unsigned char* g1 = gbase + (tail ? r_lane[1] : w_lane + 3072u);
             unsigned char* lw = smem + KS * W_STEP + wid * 6144;
             f32x4 y0 = x0, y1 = x1;
 #pragma unroll
@@ -309,9 +318,9 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                         acc[m][n] = mma16(ah, bh[n], acc[m][n]);
                     }
                     if (m == 0) {       // the six W pieces of step s + 2, two behind each triplet of the first row block
-                        if (n == 0) { glds16<0>(gw, lw); glds16<1024>(gw, lw); }
-                        if (n == 1) { glds16<2048>(gw, lw); glds16<3072>(gw, lw); }
-                        if (n == 2) { glds16<0>(gw + 4096, lw + 4096); glds16<1024>(gw + 4096, lw + 4096); }
+                        if (n == 0) { glds16<0>(g0, lw); glds16<1024>(g0, lw); }
+                        if (n == 1) { glds16<2048>(g0, lw); glds16<0>(g1, lw + 3072); }
+                        if (n == 2) { glds16<1024>(g1, lw + 3072); glds16<2048>(g1, lw + 3072); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -321,10 +330,12 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                         E3D_VMCNT(12);     // A(p+1) has landed (issued a pair ago; W(2p+2), W(2p+3) behind it may fly)
                         E3D_BARRIER();
                         RSTAMP(stamp_step, 4);
-                        const unsigned char* ga = reinterpret_cast<const unsigned char*>(a_tile + a_pair_next * 32);
-                        unsigned char* la = smem + LDS_A + a_nx2 + wid * 1024;
-                        glds16<0>(ga + a_lane[0], la);
-                        glds16<0>(ga + a_lane[1], la + 8192);
+                        if (a_pair_next >= 0) {     // (the last pair fetches nothing: its buffer is the residual ring's third)
+                            const unsigned char* ga = reinterpret_cast<const unsigned char*>(a_tile + a_pair_next * 32);
+                            unsigned char* la = smem + LDS_A + a_nx2 + wid * 1024;
+                            glds16<0>(ga + a_lane[0], la);
+                            glds16<0>(ga + a_lane[1], la + 8192);
+                        }
                     }
                     E3D_VMCNT(8);          // W(s+1) has landed (issued a step ago); the 6 + 2 pieces behind it may fly
                     RSTAMP(stamp_step, 3);
@@ -346,14 +357,16 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
         };
 
         for (int p = 0; p < npairs; ++p) {
-            step(std::integral_constant<int, 0>{}, bh0, bl0, bh1, bl1, min(2 * p + 2, last_step), 0, 2 * p);
-            step(std::integral_constant<int, 1>{}, bh1, bl1, bh0, bl0, min(2 * p + 3, last_step), min(p + 2, npairs - 1), 2 * p + 1);
+            const bool last_pair = p + 1 == npairs;
+            step(std::integral_constant<int, 0>{}, bh0, bl0, bh1, bl1, min(2 * p + 2, last_step), 0, last_pair && res_on ? 0 : -1, 2 * p);
+            step(std::integral_constant<int, 1>{}, bh1, bl1, bh0, bl0, min(2 * p + 3, last_step), last_pair ? -1 : min(p + 2, npairs - 1),
+                 last_pair && res_on ? 1 : -1, 2 * p + 1);
             const int t = a_cur;
             a_cur = a_nxt;
             a_nxt = a_nx2;
             a_nx2 = t;
         }
-        E3D_VMCNT(0);              // the re-fetched W steps / A pairs of the tail
+        if (!res_on) E3D_VMCNT(0);     // the re-fetched W steps of the tail (with a residual: its chunks 0 and 1 -- let them fly)
         E3D_LDS_BARRIER();
         TSTAMP(2);
 
@@ -365,13 +378,11 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
             for (int n = 0; n < 3; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = fmaf(acc[m][n][r], out_scale, colc[colbase + 32 * n]);
-        if (res && !(ROWLN_LAB & 1)) {
+        if (res_on) {
             // ring of three 16-row chunks: chunk c = tile rows [16 c, 16 c + 16) = m-block c >> 1, accumulator registers
-            // 8 (c & 1) .. +8 of every wave's three column blocks
-            const unsigned char* rt = reinterpret_cast<const unsigned char*>(res + (int64_t)row0 * ldr);
-            const int64_t chunk_stride = 16 * ldr * 4;
+            // 8 (c & 1) .. +8 of every wave's three column blocks; chunks 0 and 1 were requested by the k loop's last two steps
             auto issue_r = [&](int c) {
-                const unsigned char* g = rt + c * chunk_stride;
+                const unsigned char* g = res_tile + c * res_chunk_stride;
                 unsigned char* l = smem + (c % 3) * RES_CHUNK + wid * 6144;
                 glds16<0>(g + r_lane[0], l);
                 glds16<1024>(g + r_lane[0], l);
@@ -381,8 +392,6 @@ __global__ __launch_bounds__(512, 2) void gemm_rowln_kernel(const float* __restr
                 glds16<2048>(g + r_lane[1], l + 3072);
             };
             constexpr int NCH = 2 * NM;
-            issue_r(0);
-            issue_r(1);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c + 1 < NCH) E3D_VMCNT(6);
