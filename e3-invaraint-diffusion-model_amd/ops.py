@@ -524,9 +524,11 @@ def residual_layernorm(x, residual, gamma, beta, eps, want_s=False, drop=None):
 # Row-complete GEMM + bias + residual + LayerNorm (csrc/gemm_rowln.hip): BertSelfOutput / BertOutput in ONE launch at large
 # M -- a workgroup owns whole 768-wide rows, the pre-norm sum never leaves its registers.  The weight goes in PRE-SPLIT
 # into its two 16-bit terms (fragment-order planes, built once per weight version by a small kernel and cached on the
-# weight like every derived-weight cache).  From ROWLN_MIN_M rows upwards (one 128-row group per CU and more; below that
-# the unfused pair's 256 x 256 / 128 x 128 tiles fill the chip better); E3D_GEMM_ROWLN=0 switches the path off (A/B runs).
-ROWLN_MIN_M = int(os.environ.get("E3D_GEMM_ROWLN_MIN_M", "32768")) if os.environ.get("E3D_GEMM_ROWLN", "1") == "1" else 1 << 62
+# weight like every derived-weight cache).  From ROWLN_MIN_M rows upwards: measured against the pair in one process
+# (tools/lab/rowln_ab.py, f16x3, K = 768 / 1024): M = 65536 257 / 319 us against 323 / 376, M = 32768 137 / 172 against
+# 168 / 208, M = 16384 66 / 83 against 84 / 98, M = 8192 41 / 51 against 53 / 61 (one 32-row tile per CU); smaller launches stay
+# on the skinny / 128 x 128 forms.  E3D_GEMM_ROWLN=0 switches the path off (A/B runs).
+ROWLN_MIN_M = int(os.environ.get("E3D_GEMM_ROWLN_MIN_M", "8192")) if os.environ.get("E3D_GEMM_ROWLN", "1") == "1" else 1 << 62
 
 
 def weight_planes(weight, terms):
