@@ -92,6 +92,12 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* const* __restrict__ pa
                                                    AdamScalars a, const float* __restrict__ dyn) {
     if (dyn) {   // learning rate and step count from device memory (a captured graph cannot carry them as arguments)
         a.lr = dyn[0];
+        if (a.beta1 < 0.f) {   // e3d_adamw_step_dev: the other hyper-parameters too (OneCycleLR cycles beta1 every step)
+            a.beta1 = dyn[2];
+            a.beta2 = dyn[3];
+            a.eps = dyn[4];
+            a.weight_decay = dyn[5];
+        }
         const double step = (double)dyn[1] + 1.0;
         a.bc1 = (float)(1.0 - pow((double)a.beta1, step));
         a.bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, step));
@@ -166,4 +172,17 @@ extern "C" int e3d_adamw_step_dyn(float* const* params, const float* const* grad
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, numel,
                        chunk_tensor, chunk_first, norm_and_clip, a, lr_and_step);
     return e3d_launch_status("e3d_adamw_step_dyn");
+}
+
+extern "C" int e3d_adamw_step_dev(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                  const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first, int n_chunks,
+                                  const float* norm_and_clip, const float* hyper, void* stream) {
+    E3D_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && chunk_tensor && chunk_first && hyper,
+                "adamw_step_dev: null pointer");
+    E3D_REQUIRE(n_chunks > 0, "adamw_step_dev: no chunks");
+    AdamScalars a;
+    a.lr = 0.f; a.beta1 = -1.f; a.beta2 = 0.f; a.eps = 0.f; a.weight_decay = 0.f; a.bc1 = 1.f; a.bc2_sqrt = 1.f;
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, numel,
+                       chunk_tensor, chunk_first, norm_and_clip, a, hyper);
+    return e3d_launch_status("e3d_adamw_step_dev");
 }

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "e3d_optim_chunk_elems": (c_int, []),
     "e3d_grad_global_norm": (c_int, [_P, _P, _P, _P, c_int, c_float, _P, _P, _P]),
     "e3d_adamw_step_dyn": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, c_float, c_float, c_float, c_float, _P]),
+    "e3d_adamw_step_dev": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "e3d_dropout_set_epoch_ptr": (c_int, [_P]),
     "e3d_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
 }

@@ -15,6 +15,9 @@ import torch
 from . import hip
 
 
+DYN_STRIDE = 8       # floats per parameter range in the device-side scalar table
+
+
 class ClipAdamW(torch.optim.AdamW):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -34,9 +37,10 @@ class ClipAdamW(torch.optim.AdamW):
         return self.last_norm
 
     def use_device_scalars(self, on=True):
-        """Keep the learning rate and the step count of every parameter range in device memory (``e3d_adamw_step_dyn``)
-        so that a captured HIP graph of the step can be replayed: ``sync_lr()`` before a replay pushes a changed learning
-        rate, ``note_replayed_step()`` after it does the host-side bookkeeping ``step()`` would have done."""
+        """Keep every scalar of the update -- learning rate, step count, betas, eps, weight decay -- of every parameter range
+        in device memory (``e3d_adamw_step_dev``) so that a captured HIP graph of the step can be replayed: ``sync_lr()``
+        before a replay pushes whatever a scheduler changed (OneCycleLR moves beta1 with the learning rate),
+        ``note_replayed_step()`` after it does the host-side bookkeeping ``step()`` would have done."""
         if bool(on) != self.device_scalars:
             self.device_scalars = bool(on)
             self._e3d_tab = None
@@ -46,10 +50,19 @@ class ClipAdamW(torch.optim.AdamW):
         if tab is None or "dyn" not in tab:
             return
         for r, (gi, _, _) in enumerate(tab["dyn_ranges"]):
-            lr = float(self.param_groups[gi]["lr"])
-            if tab["dyn_lr"][r] != lr:
-                tab["dyn_lr"][r] = lr
-                tab["dyn"][r, 0:1].fill_(lr)
+            hyper = self._hyper(self.param_groups[gi])
+            if tab["dyn_hyper"][r] != hyper:
+                if tab["dyn_hyper"][r][0] != hyper[0]:
+                    tab["dyn"][r, 0:1].fill_(hyper[0])
+                if tab["dyn_hyper"][r][1:] != hyper[1:]:
+                    tab["dyn"][r, 2:6].copy_(torch.tensor(hyper[1:], dtype=torch.float32), non_blocking=False)
+                tab["dyn_hyper"][r] = hyper
+
+    @staticmethod
+    def _hyper(group):
+        """(lr, beta1, beta2, eps, weight_decay) of a parameter group as the kernels see them (fp32 values)."""
+        b1, b2 = group["betas"]
+        return tuple(float(torch.tensor(float(x), dtype=torch.float32)) for x in (group["lr"], b1, b2, group["eps"], group["weight_decay"]))
 
     def note_replayed_step(self, delta=1):
         """Host-side bookkeeping of one replayed step (``delta=-1``: undo that of a capture pass, which runs ``step()`` on
@@ -80,7 +93,12 @@ class ClipAdamW(torch.optim.AdamW):
         if self._e3d_clip is not None:
             params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
             self.last_norm = torch.nn.utils.clip_grad_norm_(params, self._e3d_clip) if params else None
-        return torch.optim.AdamW.step(self, closure)
+        self._e3d_tab = None      # torch advances state["step"] itself: the cached ranges / device counts would be stale
+        # (the undecorated implementation: this call already runs inside the hooked ClipAdamW.step, so going through a
+        #  hooked torch.optim.AdamW.step -- patched as soon as a plain AdamW exists in the process -- would fire every
+        #  optimizer pre / post hook twice)
+        plain = getattr(torch.optim.AdamW.step, "__wrapped__", torch.optim.AdamW.step)
+        return plain(self, closure)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -133,11 +151,11 @@ class ClipAdamW(torch.optim.AdamW):
                 lr = group["lr"]
                 r += 1
                 if self.device_scalars:
-                    hip.check(lib.e3d_adamw_step_dyn(
+                    hip.check(lib.e3d_adamw_step_dev(
                         tab["pptr"].data_ptr(), tab["gptr"].data_ptr(), tab["mptr"].data_ptr(), tab["vptr"].data_ptr(),
                         tab["numel"].data_ptr(), tab["chunk_tensor"].data_ptr() + 4 * c0, tab["chunk_first"].data_ptr() + 8 * c0,
-                        c1 - c0, nc.data_ptr() if nc is not None else None, tab["dyn"].data_ptr() + 8 * r, float(b1), float(b2),
-                        float(group["eps"]), float(group["weight_decay"]), stream), "e3d_adamw_step_dyn")
+                        c1 - c0, nc.data_ptr() if nc is not None else None, tab["dyn"].data_ptr() + 4 * DYN_STRIDE * r, stream),
+                        "e3d_adamw_step_dev")
                     continue
                 hip.check(lib.e3d_adamw_step(
                     tab["pptr"].data_ptr(), tab["gptr"].data_ptr(), tab["mptr"].data_ptr(), tab["vptr"].data_ptr(),
@@ -220,7 +238,9 @@ class ClipAdamW(torch.optim.AdamW):
         if self.device_scalars:
             flat = [(gi, c0, st) for (gi, _), rs in zip(parts, ranges) for (c0, c1, st) in rs]
             tab["dyn_ranges"] = flat
-            tab["dyn_lr"] = [float(self.param_groups[gi]["lr"]) for gi, _, _ in flat]
-            tab["dyn"] = torch.tensor([[lr, float(st)] for lr, (_, _, st) in zip(tab["dyn_lr"], flat)], dtype=torch.float32).to(dev)
+            tab["dyn_hyper"] = [self._hyper(self.param_groups[gi]) for gi, _, _ in flat]
+            # per range: lr, steps taken, beta1, beta2, eps, weight_decay, (2 pad) -- e3d_adamw_step_dev's ``hyper`` block
+            tab["dyn"] = torch.tensor([[h[0], float(st), h[1], h[2], h[3], h[4], 0.0, 0.0] for h, (_, _, st) in zip(tab["dyn_hyper"], flat)],
+                                      dtype=torch.float32).to(dev)
         self._e3d_tab = tab
         return tab

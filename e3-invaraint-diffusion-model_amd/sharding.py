@@ -131,6 +131,34 @@ class GradientAverager:
         self._pending = [len(b) for b in self.buckets]
         self._handles, self._bound, self._touched = {}, True, set()
 
+    # ---- graph-segment form (training.GraphedDDPStep): the same buckets, no collective launched from a hook
+    def bind(self, collect_only=False):
+        """``prepare`` for a backward pass that is being CAPTURED: every ``.grad`` becomes a zeroed view of its bucket (the
+        zero fills are captured with the pass), the hooks only note which parameters the pass touches."""
+        for i, bucket in enumerate(self.buckets):
+            flat = self._buffer(i)
+            flat.zero_()
+            off = 0
+            for p in bucket:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self._pending = [1 << 30] * len(self.buckets) if collect_only else [len(b) for b in self.buckets]
+        self._handles, self._bound, self._touched = {}, True, set()
+
+    def finish_collect(self):
+        self._bound = False
+        self._drop_unused()
+
+    def flats(self):
+        return [self._flat[i] for i in range(len(self.buckets))]
+
+    def all_reduce_flats(self):
+        """Sum every bucket over the ranks (the division by the world size belongs to the caller's captured segment);
+        asynchronous on the wire, in bucket order, joined before returning to the caller's stream."""
+        works = [dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True) for i in range(len(self.buckets))]
+        for w in works:
+            w.wait()
+
     def _drop_unused(self):
         """A parameter no rank's backward touched (the hook never fired anywhere: the autograd graph is the same
         on every rank) gets ``grad = None`` back, as in a single-process run: the optimizer then skips it

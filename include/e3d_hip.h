@@ -453,6 +453,9 @@ int e3d_gemm_residual_layernorm_f32_split(const float* A, int64_t lda, const voi
 /*   e3d_adamw_step_dyn: the same update with the learning rate and the step count read from DEVICE memory
  *     (lr_and_step[0] = lr, lr_and_step[1] = number of steps taken BEFORE this one, as a float) -- the form a captured HIP
  *     graph of the training step replays: the caller advances lr_and_step[1] on the device after the launch.
+ *   e3d_adamw_step_dev (ABI v4): EVERY scalar of the update from device memory -- hyper[0..5] = lr, steps taken before this
+ *     one, beta1, beta2, eps, weight_decay -- so that a replayed graph follows schedulers that move more than the learning
+ *     rate (torch's OneCycleLR cycles beta1 with it: structure_model/model.py:372, sequence_model/model.py:425).
  *   e3d_dropout_set_epoch_ptr: registers (per device; NULL unregisters) a device word every dropout launch adds to its
  *     seed INSIDE the kernel (e3d_dropout_f32, e3d_relkey_attn_fwd_split_drop / _ex, e3d_relkey_attn_bwd_drop / _ex,
  *     e3d_attn_dropout_mask): a replayed graph bakes the seed arguments, so the training step advances this word instead
@@ -461,6 +464,9 @@ int e3d_adamw_step_dyn(float* const* params, const float* const* grads, float* c
                        const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first, int n_chunks,
                        const float* norm_and_clip, const float* lr_and_step, float beta1, float beta2, float eps,
                        float weight_decay, void* stream);
+int e3d_adamw_step_dev(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first, int n_chunks,
+                       const float* norm_and_clip, const float* hyper, void* stream);
 int e3d_dropout_set_epoch_ptr(const uint64_t* device_word);
 int e3d_optim_chunk_elems(void);
 int e3d_grad_global_norm(const float* const* grads, const int64_t* numel, const int* chunk_tensor, const int64_t* chunk_first,

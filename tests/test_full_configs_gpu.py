@@ -96,6 +96,19 @@ def report_grad_errors(tag, errs, capsys):
 
 
 # ------------------------------------------------------------------------------------ config 1
+_CONFIG1_ORACLE = {}
+
+
+def _config1_oracle(sd, pk, x_T, noises, betas, T, L):
+    """The CPU oracle's 50-step chain: the same for every arithmetic mode of the test below (same seeds), ~35 s of host
+    time -- computed once per session instead of once per mode."""
+    if "want" not in _CONFIG1_ORACLE:
+        fn = lambda t, x, lm, rs, ra, rm: ostr.forward(sd, {"num_heads": 12, "max_pos": L}, t, x, lm, rs, ra, rm)  # noqa: E731
+        _CONFIG1_ORACLE["want"] = ostr.p_sample_loop(fn, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"],
+                                                     pk["receptor_angles"], T, betas, noises=noises)
+    return _CONFIG1_ORACLE["want"]
+
+
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])
 def test_config1_single_pocket_64_residues_50_steps(pkg, hip, mode, capsys):
     """BASELINE configs[0] at its full size on the GPU: ONE 64-residue pocket, the full 12+12-layer model, all 50
@@ -110,9 +123,7 @@ def test_config1_single_pocket_64_residues_50_steps(pkg, hip, mode, capsys):
     x_T = ostr.modulo_with_wrapped_range(torch.randn(B, L, 8, generator=g))
     noises = torch.randn(T, B, L, 8, generator=g)
     betas = ostr.cosine_beta_schedule(T)
-    fn = lambda t, x, lm, rs, ra, rm: ostr.forward(sd, {"num_heads": 12, "max_pos": L}, t, x, lm, rs, ra, rm)  # noqa: E731
-    want = ostr.p_sample_loop(fn, pk["ligand_attn_mask"], x_T, pk["receptor_seq"], pk["receptor_attn_mask"],
-                              pk["receptor_angles"], T, betas, noises=noises)
+    want = _config1_oracle(sd, pk, x_T, noises, betas, T, L)
     with pkg.ops.arithmetic(mode, respect_env=False):
         teacher_forced_steps(model, to_dev(pk), x_T, want, noises, betas, T)
         # the loop entry point itself at this size: same chain, free-running, finite and wrapped

@@ -101,6 +101,19 @@ def _worker(rank, world, port, q):
     assert all(p.grad is not None for p in used)
     assert torch.allclose(model["a"].weight.grad, sum(both) / world)
     assert model["unused"].weight.grad is None
+    # ---- the graph-segment form (training.GraphedDDPStep): backward into the bucket views with NO collective from the
+    # hooks (that pass is captured), the buckets summed afterwards in one place, the division left to the caller's segment
+    for p in model.parameters():
+        p.grad = None
+    avg.bind(collect_only=True)
+    model["b"](model["a"](x)).sum().backward()
+    assert len(avg._handles) == 0                     # nothing on the wire yet
+    avg.finish_collect()
+    assert model["unused"].weight.grad is None and model["a"].weight.grad is not None
+    avg.all_reduce_flats()
+    for flat in avg.flats():
+        flat.div_(world)
+    assert torch.allclose(model["a"].weight.grad, sum(both) / world)
     w0 = [torch.zeros_like(model["a"].weight) for _ in range(world)]
     torch.distributed.all_gather(w0, model["a"].weight.data)
     assert torch.equal(w0[0], w0[1])

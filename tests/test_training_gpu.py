@@ -256,7 +256,7 @@ def _structure_batches(n, B=8, L=64):
 def test_graph_replayed_training_step_matches_the_eager_step(pkg, hip):
     """training.GraphedStep (what ``training.fit`` runs for a single process): two eager steps, capture, replays -- against
     plain eager steps on a twin model with the same batches: per-step losses and the parameters after 10 steps agree, with a
-    learning rate that changes every step (device-side scalar), a ragged batch in the middle (eager, then replays again) and
+    learning rate AND a beta1 that change every step (device-side scalars: OneCycleLR cycles both), a ragged batch in the middle (eager, then replays again) and
     the optimizer's step counts where torch's AdamW would have them."""
     from e3diff_amd import autograd, ops, training
     batches = _structure_batches(10)
@@ -270,6 +270,9 @@ def test_graph_replayed_training_step_matches_the_eager_step(pkg, hip):
         with ops.arithmetic("bf16x3"):
             for k, batch in enumerate(batches):
                 optim.param_groups[0]["lr"] = 1e-3 * (1 + 0.25 * k)
+                # ... and a momentum that moves with it, as torch's OneCycleLR (cycle_momentum=True, the reference's
+                # lr_scheduler="OneCycleLR": structure_model/model.py:372) rewrites betas[0] every step between 0.85 and 0.95
+                optim.param_groups[0]["betas"] = (0.95 - 0.01 * k, 0.999)
                 if graphed:
                     # freed caching-allocator blocks full of a poison value between replays: a captured step that reads
                     # memory it does not own (hipMemsetAsync nodes did not clear their destinations reliably inside a

@@ -63,9 +63,15 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
 
     # as training.fit does for a single process: the step replayed from a HIP graph (training.GraphedStep) after two eager
     # steps; ``graph=False`` / E3D_TRAIN_GRAPH=0: eager
-    graph = (pkg.training.GRAPH_TRAIN if graph is None else graph) and not ddp and isinstance(optim, pkg.optim.ClipAdamW)
-    stepper = pkg.training.GraphedStep(model, optim, params, 1.0) if graph else None
-    warmup = max(warmup, 4) if graph else warmup
+    graph = (pkg.training.GRAPH_TRAIN if graph is None else graph) and isinstance(optim, pkg.optim.ClipAdamW)
+    stepper = None
+    if graph and not ddp:
+        stepper = pkg.training.GraphedStep(model, optim, params, 1.0)
+    elif graph and ddp and averager._active() and averager._hooked:
+        # as training.fit does under a process group: forward + backward and clip + AdamW as two graph segments around the
+        # eager all-reduce of the gradient buckets (training.GraphedDDPStep)
+        stepper = pkg.training.GraphedDDPStep(model, optim, params, 1.0, averager)
+    warmup = max(warmup, 4) if stepper is not None else warmup
 
     def step():
         if model_name == "structure":
