@@ -9,6 +9,12 @@
 //
 // k-order trick: a lane (row r, half h) takes one float4 = k {8s+4h .. 8s+4h+3} and feeds element
 // kk to MFMA kk; A and B use the same map, so each MFMA still pairs equal k.
+//
+// Blocked accumulation (round 4): every 32-deep k-tile is summed into a fresh partial accumulator (a chain of 16
+// two-product MFMAs) which is then added to the running sum -- K / 32 + 16 roundings per output instead of one serial
+// chain of K / 2 (384 at K = 768).  The serial chain was where this "exact fp32" kernel lost a factor of two against the
+// CPU's blocked sgemm (teacher-forced per stage against the fp64 oracle: 1.5-2.0e-6 here, 0.7-0.9e-6 on the CPU, and
+// 1.0e-6 for f16x3, whose MFMAs sum 16 products internally: profiles/r04_margin_bisect_x2_before.log).
 #include "e3d_common.h"
 
 namespace {
@@ -86,6 +92,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32(const float* __restrict__ A, 
         }
         const float* as = As + cur * TILE_F + a_frag;
         const float* bs = Bs + cur * TILE_F + b_frag;
+        f32x16 part[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[m][n][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             f32x4 fa[2], fb[2];
@@ -101,9 +114,13 @@ __global__ __launch_bounds__(256) void gemm_nt_f32(const float* __restrict__ A, 
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][kk], fb[n][kk],
-                                                                         acc[m][n], 0, 0, 0);
+                        part[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][kk], fb[n][kk],
+                                                                          part[m][n], 0, 0, 0);
         }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] += part[m][n];
         if (more) {
             float* ad = As + (cur ^ 1) * TILE_F;
             float* bd = Bs + (cur ^ 1) * TILE_F;

@@ -412,9 +412,10 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
 
     The scaled regimes sharpen the softmax rows (attention logits x4 / x16) and are ill-conditioned for ANY fp32
     implementation: the CPU oracle in fp32 is itself ~3e-5..8e-5 (x2) / ~4e-4..7e-4 (x4, depending on the thread count's
-    summation order) away from the same oracle in fp64 (tools/lab/margin_cpu.py).  They are therefore ranked against the fp64 oracle, and asserted RELATIVE to the exact
-    fp32 MFMA kernels: the fp32-grade split arithmetics (f16x3, bf16x6) must stay within a small factor of the f32
-    figure -- x2: <= 2x, x4: <= 10x (measured on MI355X, vs fp64: x2 f32 1.5e-4, f16x3 8.0e-5, bf16x6 1.2e-4,
+    summation order) away from the same oracle in fp64 (tools/lab/margin_cpu.py).  They are ranked against the fp64 oracle.
+    x2 and the heavy-tailed regime are asserted ABSOLUTELY for the inference default (f16x3 <= 1e-4 against the fp32 oracle
+    and against fp64); x4 relative to what exact fp32 achieves there (<= 10x) (measured on MI355X in round 3, vs fp64: x2 f32 1.5e-4 -- 5e-5
+    since round 4's blocked accumulation --, f16x3 8.0e-5, bf16x6 1.2e-4,
     bf16x3 6.5e-4; x4 f32 8.0e-4, f16x3 5.5e-4, bf16x6 2.6e-3, bf16x3 0.12 -- at x4 the first encoder layer sees
     activations of ~5000 and logits of ~1e7, where a 2^-17 product error is an absolute logit error of ~100).  (Round 2 reported 0.47 for every split arithmetic at x4 and called it
     ill-conditioning; it was a defect -- the attention kernels skipped all-padding key tiles although the first encoder
@@ -449,7 +450,11 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
         for mode, (mx, mx64, p999, emax) in rows.items():
             print(f"\n[margin, {regime}, L=256 12+12, {mode}] max-norm vs fp32 oracle {mx:.2e}, vs fp64 oracle {mx64:.2e} | "
                   f"element-wise (fp64) p99.9 {p999:.2e} max {emax:.2e}")
-    f32 = max(rows["f32"][1], rows["cpu-f32"][1])      # what an exact-fp32 implementation achieves here (GPU or CPU)
+    cpu = rows["cpu-f32"][1]                           # the CPU oracle in fp32 against the same oracle in fp64
+    f32 = max(rows["f32"][1], cpu)                     # what an exact-fp32 implementation achieves here (GPU or CPU)
+    # the exact-fp32 kernels are fp32-grade in EVERY regime: within 2x of the CPU's own fp32 (round 4: blocked accumulation
+    # in gemm_nt_f32 -- with one serial chain over K the kernel sat at 4.4x the CPU figure in the x2 regime)
+    assert rows["f32"][1] < 2 * cpu + 1e-6, rows
     if scale == 1.0:
         assert rows["bf16x3"][0] < TOL and rows["bf16x6"][0] < TOL and rows["f32"][0] < TOL and rows["f16x3"][0] < TOL
         # element-wise, floor 1e-3 rms: outputs 1000x below the rms carry the same ABSOLUTE error as the large ones, so
@@ -457,11 +462,15 @@ def test_bf16x3_margin_elementwise_at_L256_full_depth(pkg, hip, regime, scale, c
         assert rows["bf16x3"][2] < 2e-3 and rows["bf16x6"][2] < 2e-4
         assert rows["f16x3"][1] < 3 * f32 and rows["bf16x6"][1] < 3 * f32
     elif scale == 2.0:
-        assert rows["f16x3"][1] < 2 * f32 and rows["bf16x6"][1] < 2 * f32, rows
+        # ABSOLUTE (the north star's "within 1e-4 relative fp32"): the inference default against the fp32 oracle and
+        # against the fp64 truth; bf16x6 (3 terms of 8 bits: the large first-layer activations cost it more) within 2e-4
+        assert rows["f16x3"][0] <= TOL and rows["f16x3"][1] <= TOL and rows["f32"][0] <= TOL, rows
+        assert rows["bf16x6"][1] < 2e-4, rows
         assert rows["bf16x3"][1] < 30 * f32, rows
     elif scale < 0:
-        # the regime shaped like TRAINED weights (per-row scales, outlier entries, outlier LayerNorm channels): the
-        # fp32-grade arithmetics within 4x of the exact fp32 kernels (measured 2.0x / 1.9x)
+        # the regime shaped like TRAINED weights (per-row scales, outlier entries, outlier LayerNorm channels): every
+        # fp32-grade arithmetic within the contract, absolutely
+        assert rows["f16x3"][0] <= TOL and rows["bf16x6"][0] <= TOL and rows["f32"][0] <= TOL, rows
         assert rows["f16x3"][1] < 4 * f32 and rows["bf16x6"][1] < 4 * f32, rows
     else:
         assert rows["f16x3"][1] < 10 * f32 and rows["bf16x6"][1] < 10 * f32, rows

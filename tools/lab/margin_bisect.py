@@ -61,7 +61,7 @@ def err(got, want, mask):
     got = got.detach().cpu().view(B, L, -1)[mask]; want = want.view(B, L, -1)[mask]
     return ((got.double() - want).abs().max() / want.abs().max()).item()
 
-MODES = ("f32", "bf16x6", "f16x3", "bf16x3")
+MODES = tuple(os.environ.get("MODES", "f32,bf16x6,f16x3,bf16x3").split(","))
 if os.environ.get("NOSKIP") == "1":
     print("padded-tile skip OFF, previous =", pkg.hip.lib().e3d_attn_skip_padded_tiles(0))
 xq = obert.linear(sd64, "encoder.layer.0.attention.self.query", stages["enc0"][0]); xk = obert.linear(sd64, "encoder.layer.0.attention.self.key", stages["enc0"][0])
@@ -74,6 +74,26 @@ for gm in MODES:
             got = model(t.to(DEV), x_t.to(DEV), d["ligand_attn_mask"], d["receptor_seq"], d["receptor_angles"], d["receptor_attn_mask"])
         print(f"gemm {gm:7s} attn {am:7s}: max-norm {err(got, want64, m):.3e}", flush=True)
 
+if os.environ.get("CPU32", "1") == "1":
+    # the CPU oracle in fp32, stage by stage on the same teacher-forced inputs: the yardstick of "fp32 grade" per stage
+    F = lambda v: v.float()
+    row = []
+    with torch.no_grad():
+        (a, s_), y = stages["receptor_emb"]
+        row.append(("receptor_emb", err(ostr.se_layer(sd, "receptor_emb", F(a), F(s_), F(rec_bias), nh, mp), y, mr)))
+        for i in range(12):
+            xi, y = stages[f"enc{i}"]
+            row.append((f"enc{i}", err(obert.bert_layer(sd, f"encoder.layer.{i}", F(xi), F(rec_bias), nh, mp), y, mr)))
+        (a, c), y = stages["timestep_emb"]
+        row.append(("timestep_emb", err(ostr.se_layer(sd, "timestep_emb", F(a), F(c), F(lig_bias), nh, mp), y, m)))
+        for i in range(12):
+            xi, y = stages[f"dec{i}"]
+            row.append((f"dec{i}", err(obert.bert_layer(sd, f"decoder.layer.{i}", F(xi), F(lig_bias), nh, mp, F(enc), F(rec_bias)), y, m)))
+        xi, y = stages["predictor"]
+        row.append(("predictor", err(ostr.predictor(sd, "angles_predictor", F(xi)), y, m)))
+        whole = ostr.forward(sd, {"num_heads": nh, "max_pos": mp}, t, x_t, pk["ligand_attn_mask"], pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
+    print("cpu32 whole forward: max-norm %.3e" % err(whole, want64, m), flush=True)
+    print("cpu32", " ".join(f"{n}:{e:.1e}" for n, e in row), flush=True)
 print("=== teacher-forced per stage (input = fp64 oracle's, cast to fp32)", flush=True)
 G = lambda v: v.float().to(DEV)
 lm, rm = d["ligand_attn_mask"].contiguous(), d["receptor_attn_mask"].contiguous()
