@@ -255,110 +255,9 @@ def run_layer(layer, x, mask, B, L, cross_kv=None, enc_mask=None, Lk=None, drop=
                                        layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.eps, drop[0])
 
 
-# ----------------------------------------------------------------------------- deferred LayerNorm (inference, large M)
-# Built, correct (tests/test_deferred_ln_gpu.py) and measured SLOWER on MI355X: 76.2 against 69.0 ms per 256 x 256 sampling
-# step.  The consumer side costs ~2 %, but the producer's epilogue has to fetch 128 residual elements per lane with no
-# registers left to keep more than a few loads in flight (413 us per launch against 211-268 for the plain kernel plus
-# 98 for the LayerNorm pass it replaces): the standalone LayerNorm streams at 6.2 TB/s, an epilogue cannot.  Off by
-# default; E3D_DEFER_LN=1 runs it.
-DEFER_LN = os.environ.get("E3D_DEFER_LN", "0") == "1"
-
-
-class _Deferred:
-    """A hidden state kept as its pre-norm sum ``z`` [M,H] + per-row (mean, rstd) + the LayerNorm's gamma / beta: what the
-    deferred path hands from block to block instead of LayerNorm(z) (include/e3d_hip.h, "deferred LayerNorm")."""
-    __slots__ = ("z", "stats", "gamma", "beta")
-
-    def __init__(self, z, stats, gamma, beta):
-        self.z, self.stats, self.gamma, self.beta = z, stats, gamma, beta
-
-    def materialise(self):
-        return ops.layernorm_from_stats(self.z, self.stats, self.gamma, self.beta)
-
-
-_IDENTITY = {}
-
-
-def _identity_ln(M, H, device):
-    """(stats, gamma, beta) under which "LayerNorm" is the identity: a plain residual through the producer epilogue."""
-    key = (device, M, H)
-    ent = _IDENTITY.get(key)
-    if ent is None:
-        stats = torch.zeros((M, 2), device=device, dtype=torch.float32)
-        stats[:, 1] = 1.0
-        ent = _IDENTITY[key] = (stats, torch.ones(H, device=device), torch.zeros(H, device=device))
-        if len(_IDENTITY) > 8:
-            _IDENTITY.pop(next(iter(_IDENTITY)))
-    return ent
-
-
-def _consume(h, weight, bias, act=ops.ACT_NONE, absmax=None):
-    """act(LayerNorm-or-plain(h) W^T + b): the consumer GEMM normalises a deferred ``h`` while staging it."""
-    if isinstance(h, _Deferred):
-        w, b = ops.folded_linear(weight, bias, h.gamma, h.beta)
-        out = ops.gemm_ln(h.z, w, b, act, absmax=absmax, a_stats=h.stats)
-    else:
-        out = ops.gemm(h, weight, bias, act, absmax=absmax)
-    if absmax is not None:
-        out._e3d_absmax = absmax
-    return out
-
-
-def _produce(a, dense, h, ln, eps):
-    """BertSelfOutput / BertOutput without their LayerNorm pass: z = a W^T + b + LayerNorm-or-plain(h) in ONE launch (the
-    residual is rebuilt in the GEMM's epilogue), returned with its row statistics as the next deferred state."""
-    if isinstance(h, _Deferred):
-        res, stats, g, b = h.z, h.stats, h.gamma, h.beta
-    else:
-        res = h
-        stats, g, b = _identity_ln(h.shape[0], h.shape[1], h.device)
-    z = ops.gemm_ln(a, dense.weight, dense.bias, res=res, res_stats=stats, res_gamma=g, res_beta=b)
-    return _Deferred(z, ops.row_stats(z, eps), ln.weight, ln.bias)
-
-
-def _deferred_ok(encoder, x, enc=None):
-    """The deferred path serves inference at sizes where every GEMM of a layer runs the persistent 256x256 kernel."""
-    if not DEFER_LN or torch.is_grad_enabled() or encoder.training or not x.is_cuda or x.dim() != 2 or not x.is_contiguous():
-        return False
-    cfg = encoder.config
-    M, H, I = x.shape[0], cfg.hidden_size, cfg.intermediate_size
-    if H not in (256, 512, 768, 1024) or not ops.gemm_ln_supported(M, H, H, x):
-        return False
-    shapes = [(3 * H, H), (H, H), (I, H), (H, I)]
-    return all(ops.gemm_ln_supported(M, n, k, x) for n, k in shapes)
-
-
-def _run_layer_deferred(layer, h, mask, B, L, cross_kv=None, enc_mask=None, Lk=None):
-    att = layer.attention
-    sa = att.self
-    w, b = qkv_weights(sa)
-    qkv = _consume(h, w, b, absmax=ops.absmax_slot(sa, "qkv", mask.device))
-    relkey = sa.position_embedding_type == "relative_key"
-    ctx = F.attention(qkv, None, B, att.num_heads, L, L, key_mask=mask,
-                      dist_emb=sa.distance_embedding.weight if relkey else None, max_pos=sa.max_position_embeddings)
-    h = _produce(ctx, att.output.dense, h, att.output.LayerNorm, att.eps)
-    if hasattr(layer, "crossattention"):
-        ca = layer.crossattention
-        q = _consume(h, ca.self.query.weight, ca.self.query.bias, absmax=ops.absmax_slot(ca.self, "q", mask.device))
-        ctx = F.attention(q, cross_kv, B, ca.num_heads, L, Lk, key_mask=enc_mask)
-        h = _produce(ctx, ca.output.dense, h, ca.output.LayerNorm, ca.eps)
-    inter = _consume(h, layer.intermediate.dense.weight, layer.intermediate.dense.bias, ops.ACT_GELU)
-    return _produce(inter, layer.output.dense, h, layer.output.LayerNorm, layer.eps)
-
-
 def run_encoder(encoder, x, mask, B, L, enc=None, enc_mask=None, Lk=None, cross_kv=None):
     """BertEncoder(...).last_hidden_state on flat activations.  ``cross_kv`` (list, one per
     layer) short-cuts the per-layer K/V projection of ``enc``."""
-    if _deferred_ok(encoder, x):
-        # inference at large M: no LayerNorm pass inside the stack -- the hidden state travels as (pre-norm sum, row
-        # statistics) and is normalised where it is consumed; the stack's output is materialised once at the end
-        h = x
-        for i, layer in enumerate(encoder.layer):
-            kv = None
-            if hasattr(layer, "crossattention"):
-                kv = cross_kv[i] if cross_kv is not None else project_cross_kv(layer.crossattention, enc)
-            h = _run_layer_deferred(layer, h, mask, B, L, kv, enc_mask, Lk)
-        return h.materialise() if isinstance(h, _Deferred) else h
     drop = dropout_rates(encoder)
     for i, layer in enumerate(encoder.layer):
         kv = None

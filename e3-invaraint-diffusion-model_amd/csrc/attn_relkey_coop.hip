@@ -532,9 +532,7 @@ int launch_any(int W, const float* q, int64_t q_bs, int64_t q_rs, const float* k
                                    Lq, Lk, q_tiles, skip, bnd, drop, dropping, s)
     switch (W) {
         E3D_COOP_CASE(8);
-        E3D_COOP_CASE(4);
-        E3D_COOP_CASE(2);
-        E3D_COOP_CASE(1);
+        E3D_COOP_CASE(4);      // (two- and one-wave groups were lab forms: slower than the per-wave kernel, 20-88 B/lane of scratch)
     }
 #undef E3D_COOP_CASE
     return -1;
@@ -553,8 +551,8 @@ static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float
         const char* e = getenv("E3D_ATTN_W");
         w_max = e ? atoi(e) : 8;
     }
-    int W = q_tiles % 8 == 0 ? 8 : (q_tiles % 4 == 0 ? 4 : (q_tiles % 2 == 0 ? 2 : 1));
-    while (W > w_max && W > 1) W >>= 1;
+    int W = q_tiles % 8 == 0 ? 8 : 4;       // the caller dispatches here for q_tiles % 4 == 0 only
+    if (W > w_max && w_max >= 4) W = 4;
     if (!dist_emb)
         return launch_any<false, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, P, key_mask, out, lse, B, nh,
                                     Lq, Lk, q_tiles, skip, bnd, drop, dropping, s);

@@ -822,32 +822,14 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void gemm_split256_kernel(const fl
 #define E3D_STORE_OUT(ptr, val) (*(ptr) = (val))
 #endif
 
-// Deferred LayerNorm (LN != 0; inference, large M): the hidden state between two blocks is kept as its PRE-norm sum z
-// plus per-row (mean, rstd) -- the normalised tensor is never written.
-//   LN = 1 (consumer): A is such a z; every staged A element becomes (z - mean) * rstd on its way into LDS (row constants
-//     from an LDS table, loaded one tile ahead of the k-tile stream) -- with gamma folded into the weight and beta into
-//     the bias by the caller this IS LayerNorm(z) W^T + b;
-//   LN = 2 (producer): the epilogue adds the residual LayerNorm(z_prev) = (z_prev - mean) * rstd * gamma + beta, rebuilt
-//     from z_prev, its row constants and the column's gamma / beta -- the output is the next pre-norm sum.
-struct LnArgs {
-    const float* a_stats;     // LN = 1: (mean, rstd) per row of A
-    const float* res;         // LN = 2: z_prev [M, ldr]
-    int64_t ldr;
-    const float* res_stats;   // LN = 2: (mean, rstd) per row of z_prev
-    const float* res_gamma;
-    const float* res_beta;
-};
-
-template <int ACT, typename E, int LN>
-__device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int64_t ldc, int N,
-                                                    int K, int tiles_m, int tiles_n, float* __restrict__ absmax, float out_scale,
-                                                    const LnArgs& ln) {
+template <int ACT, typename E>
+__global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ W,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int64_t ldc, int N, int K,
+                                                                 int tiles_m, int tiles_n, float* __restrict__ absmax, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NS = 2, T_BYTES = BT * ROW64, BUF_BYTES = 2 * NS * T_BYTES;
-    // LN: row constants behind the two staging buffers, [parity][256 rows] x (mean, rstd)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2* cst = reinterpret_cast<f32x2*>(smem_raw + 2 * BUF_BYTES);
     constexpr int NI = 8;   // float4 items per thread and k-tile: 0..3 from A, 4..7 from W
     const int total = tiles_m * tiles_n, nk = K / BK;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -887,36 +869,18 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
     // (the timing-only ablations and operand-format prototypes of rounds 1-2 live in
     // tools/lab/archive/gemm_split_r02_lab_switches.hip.txt: nothing in this file computes a wrong result by a -D flag)
     auto item_load = [&](int i) { rg[i] = *reinterpret_cast<const f32x4*>((i < 4 ? ld_a : ld_w) + goff[i]); };
-    auto item_store = [&](int i, unsigned char* buf, int cpar) {
+    auto item_store = [&](int i, unsigned char* buf) {
         typename Vec<E>::x4 p[NS];
-        f32x4 v = rg[i];
-        if (LN == 1 && i < 4) {   // (z - mean) * rstd with the constants of the item's row in the tile it belongs to
-            const f32x2 c = cst[cpar * BT + (tid >> 3) + 64 * i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (v[j] - c[0]) * c[1];
-        }
-        split4<NS, E>(v, p);
+        split4<NS, E>(rg[i], p);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(buf + s * T_BYTES + dst[i]) = p[s];
     };
-    // LN = 1: row constants of the A rows of tile ``t`` (this workgroup's tile stream) into table ``par``
-    auto load_consts = [&](int t, int par) {
-        if (LN == 1 && tid < BT && t < total) {
-            const int lid = xcd_remap(t, total);
-            cst[par * BT + tid] = reinterpret_cast<const f32x2*>(ln.a_stats)[(int64_t)(lid / tiles_n) * BT + tid];
-        }
-    };
-    if (LN == 1) {
-        load_consts(blockIdx.x, 0);
-        __syncthreads();
-    }
-
     cursor_bases();
 #pragma unroll
     for (int i = 0; i < NI; ++i) item_load(i);
     cursor_advance();
 #pragma unroll
-    for (int i = 0; i < NI; ++i) item_store(i, smem_raw, 0);
+    for (int i = 0; i < NI; ++i) item_store(i, smem_raw);
 #pragma unroll
     for (int i = 0; i < NI; ++i) item_load(i);
     cursor_advance();
@@ -930,7 +894,6 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
     int cur = 0;
     unsigned amax = 0;   // largest |out| of this lane over all its tiles (absmax != nullptr)
 
-    int tpar = 0;   // LN = 1: parity of this tile's ordinal in the workgroup's stream = its constants table
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -939,14 +902,9 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-        // the next tile's constants, one tile ahead: its first k-tile is staged during THIS tile's last k-step (the other
-        // table was last read while the previous tile's k-tiles were staged; >= 1 k-step barrier before the first use)
-        load_consts(tile + (int)gridDim.x, tpar ^ 1);
-
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned char* base = smem_raw + cur * BUF_BYTES;
             unsigned char* next = smem_raw + (cur ^ 1) * BUF_BYTES;
-            const int cpar = kt + 1 < nk ? tpar : tpar ^ 1;   // the k-tile staged in this step belongs to this / the next tile
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 typename Vec<E>::x8 fa[NS][4], fb[NS][2];
@@ -963,7 +921,7 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int g = ks * 4 + m;   // MFMA group g stages item g: stream k-tile +1 out, +2 in
-                    item_store(g, next, cpar);
+                    item_store(g, next);
                     item_load(g);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
@@ -983,11 +941,6 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
         // kernel free of scratch spills: the n-outer order with one bias load per column block cost 12-36 B/lane)
         const int lid = xcd_remap(tile, total);
         const int row0 = (lid / tiles_n) * BT, col0 = (lid % tiles_n) * BT;
-        tpar ^= 1;
-        if (LN == 2) {   // row constants of z_prev for this tile's 256 rows (every wave is past the k loop's last barrier)
-            if (tid < BT) cst[tid] = reinterpret_cast<const f32x2*>(ln.res_stats)[row0 + tid];
-            __syncthreads();
-        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -995,16 +948,9 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
                 const int col = col0 + wc * 64 + n * 32 + l31;
                 const float bv = bias ? bias[col] : 0.f;
                 float* o = out + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * ldc + col;
-                const float* zp = LN == 2 ? ln.res + (int64_t)(row0 + wr * 128 + m * 32 + 4 * half) * ln.ldr + col : nullptr;
-                const float rg_ = LN == 2 ? ln.res_gamma[col] : 0.f, rb_ = LN == 2 ? ln.res_beta[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = fmaf(acc[m][n][r], out_scale, bv);   // (out_scale = 1: acc + bv, bit for bit)
-                    if (LN == 2) {
-                        const int dr = (r & 3) + 8 * (r >> 2);
-                        const f32x2 c = cst[wr * 128 + m * 32 + 4 * half + dr];
-                        v += fmaf((zp[(int64_t)dr * ln.ldr] - c[0]) * c[1], rg_, rb_);
-                    }
                     if (ACT == E3D_ACT_GELU) v = gelu_erf(v);
                     if (ACT == E3D_ACT_SILU) v = silu(v);
                     E3D_STORE_OUT(&o[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc], v);
@@ -1016,43 +962,17 @@ __device__ __forceinline__ void gemm_split256p_body(const float* __restrict__ A,
     if (ACT == E3D_ACT_NONE && absmax) e3d_absmax_commit(amax, absmax, lane);
 }
 
-// two entry points over one body: the plain kernel keeps its round-2 signature (the LnArgs block as a kernel argument cost
-// the LN = 0 instantiation ~1 % on the dominant launches: tools/lab/gemm_two_libs_ab.py)
 template <int ACT, typename E>
-__global__ __launch_bounds__(512, 2) void gemm_split256p_kernel(const float* __restrict__ A, int64_t lda,
-                                                                 const float* __restrict__ W,
-                                                                 const float* __restrict__ bias,
-                                                                 float* __restrict__ out, int64_t ldc, int N, int K,
-                                                                 int tiles_m, int tiles_n, float* __restrict__ absmax, float out_scale) {
-    gemm_split256p_body<ACT, E, 0>(A, lda, W, bias, out, ldc, N, K, tiles_m, tiles_n, absmax, out_scale, LnArgs{});
-}
-template <int ACT, typename E, int LN>
-__global__ __launch_bounds__(512, 2) void gemm_split256p_ln_kernel(const float* __restrict__ A, int64_t lda,
-                                                                    const float* __restrict__ W,
-                                                                    const float* __restrict__ bias,
-                                                                    float* __restrict__ out, int64_t ldc, int N, int K,
-                                                                    int tiles_m, int tiles_n, float* __restrict__ absmax, float out_scale,
-                                                                    const LnArgs ln) {
-    gemm_split256p_body<ACT, E, LN>(A, lda, W, bias, out, ldc, N, K, tiles_m, tiles_n, absmax, out_scale, ln);
-}
-
-template <int ACT, typename E, int LN = 0>
 int launch256p(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N,
-               int K, Epi epi, hipStream_t s, LnArgs ln = LnArgs{}) {
+               int K, Epi epi, hipStream_t s) {
     const int tiles_m = M / BT, tiles_n = N / BT;
-    constexpr size_t lds = 2 * 2 * 2 * BT * ROW64 + (LN ? 2 * BT * 2 * sizeof(float) : 0);
+    constexpr size_t lds = 2 * 2 * 2 * BT * ROW64;
     static std::atomic<uint64_t> lds_ok{0};
     const int n_cu = e3d_cu_count();
     const int total = tiles_m * tiles_n;
-    if constexpr (LN == 0) {
-        e3d_allow_lds(lds_ok, gemm_split256p_kernel<ACT, E>, lds);
-        hipLaunchKernelGGL((gemm_split256p_kernel<ACT, E>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias, out,
-                           ldc, N, K, tiles_m, tiles_n, epi.absmax, epi.scale);
-    } else {
-        e3d_allow_lds(lds_ok, gemm_split256p_ln_kernel<ACT, E, LN>, lds);
-        hipLaunchKernelGGL((gemm_split256p_ln_kernel<ACT, E, LN>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W,
-                           bias, out, ldc, N, K, tiles_m, tiles_n, epi.absmax, epi.scale, ln);
-    }
+    e3d_allow_lds(lds_ok, gemm_split256p_kernel<ACT, E>, lds);
+    hipLaunchKernelGGL((gemm_split256p_kernel<ACT, E>), dim3(total < n_cu ? total : n_cu), dim3(512), lds, s, A, lda, W, bias, out,
+                       ldc, N, K, tiles_m, tiles_n, epi.absmax, epi.scale);
     return e3d_launch_status("e3d_gemm_f32_split (persistent 256x256)");
 }
 
@@ -1325,45 +1245,6 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
         else go(gemm_wgrad_grouped_kernel<3, false>, lds, ok3);
     }
     return e3d_launch_status("e3d_gemm_wgrad_grouped_f32_split");
-}
-
-extern "C" int e3d_gemm_ln_supported(int M, int N, int K, int64_t lda) {
-    return M > 0 && M % BT == 0 && N % BT == 0 && K % BK == 0 && K >= 2 * BK && lda < (1 << 22);
-}
-
-extern "C" int e3d_gemm_bias_act_f32_split_ln(const float* A, int64_t lda, const float* W, const float* bias, float* out,
-                                              int64_t ldc, int M, int N, int K, int act, int terms, float* out_absmax,
-                                              float out_scale, const float* a_stats, const float* res, int64_t ldr,
-                                              const float* res_stats, const float* res_gamma, const float* res_beta,
-                                              void* stream) {
-    E3D_REQUIRE(A && W && out, "gemm_ln: null pointer");
-    E3D_REQUIRE(e3d_gemm_ln_supported(M, N, K, lda), "gemm_ln: shape outside the persistent 256x256 kernel (M=%d N=%d K=%d)", M, N, K);
-    E3D_REQUIRE(ldc >= N && lda >= K && lda % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0,
-                "gemm_ln: bad strides / alignment");
-    E3D_REQUIRE(terms == 3 || terms == E3D_TERMS_F16X3, "gemm_ln: terms must be 3 or 19 (got %d)", terms);
-    E3D_REQUIRE((a_stats != nullptr) != (res != nullptr), "gemm_ln: exactly one of a_stats (consumer) / res (producer)");
-    E3D_REQUIRE(!out_absmax || act == E3D_ACT_NONE, "gemm_ln: out_absmax exists for act = none");
-    hipStream_t s = (hipStream_t)stream;
-    const Epi epi{out_absmax, out_scale};
-    LnArgs ln{a_stats, res, ldr, res_stats, res_gamma, res_beta};
-    if (res) {
-        E3D_REQUIRE(res_stats && res_gamma && res_beta && ldr >= N && act == E3D_ACT_NONE, "gemm_ln: producer needs stats, gamma, beta, act = none");
-        if (terms == 3) return launch256p<E3D_ACT_NONE, __bf16, 2>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-        return launch256p<E3D_ACT_NONE, _Float16, 2>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-    }
-    switch (act) {
-        case E3D_ACT_NONE:
-            if (terms == 3) return launch256p<E3D_ACT_NONE, __bf16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-            return launch256p<E3D_ACT_NONE, _Float16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-        case E3D_ACT_GELU:
-            if (terms == 3) return launch256p<E3D_ACT_GELU, __bf16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-            return launch256p<E3D_ACT_GELU, _Float16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-        case E3D_ACT_SILU:
-            if (terms == 3) return launch256p<E3D_ACT_SILU, __bf16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-            return launch256p<E3D_ACT_SILU, _Float16, 1>(A, lda, W, bias, out, ldc, M, N, K, epi, s, ln);
-    }
-    e3d_set_error("gemm_ln: unknown activation %d", act);
-    return -1;
 }
 
 extern "C" int e3d_gemm_wgrad_ragged_f32_split(const float* const* dz, const float* const* x, float* const* dw, float* const* db,

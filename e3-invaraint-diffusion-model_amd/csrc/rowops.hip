@@ -77,58 +77,6 @@ __global__ __launch_bounds__(256) void residual_layernorm_kernel(
     row_store<V>(r, out + (int64_t)row * H, lane);
 }
 
-// Deferred LayerNorm (gemm_split.hip, LnArgs): (mean, rstd) of every row of a pre-norm sum z -- the same two-pass centred
-// statistics as residual_layernorm_kernel, one read of z, 8 bytes written per row.
-template <int V>
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ z, float eps, float* __restrict__ stats, int M) {
-    constexpr int H = 256 * V;
-    constexpr float inv_h = 1.0f / H;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    f32x4 r[V];
-    row_load<V>(r, z + (int64_t)row * H, lane);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < V; ++i) s += (r[i][0] + r[i][1]) + (r[i][2] + r[i][3]);
-    const float mean = wave_sum(s) * inv_h;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = r[i][j] - mean;
-            ss += d * d;
-        }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv_h + eps);
-    if (lane == 0) {
-        stats[2 * (int64_t)row] = mean;
-        stats[2 * (int64_t)row + 1] = rstd;
-    }
-}
-
-// out = (z - mean) * rstd * gamma + beta from precomputed row constants: where a consumer outside the deferred path needs
-// the normalised tensor after all
-template <int V>
-__global__ __launch_bounds__(256) void apply_stats_kernel(const float* __restrict__ z, const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ out, int M) {
-    constexpr int H = 256 * V;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    f32x4 r[V], g[V], b[V];
-    row_load<V>(r, z + (int64_t)row * H, lane);
-    row_load<V>(g, gamma, lane);
-    row_load<V>(b, beta, lane);
-    const float mean = stats[2 * (int64_t)row], rstd = stats[2 * (int64_t)row + 1];
-#pragma unroll
-    for (int i = 0; i < V; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[i][j] = (r[i][j] - mean) * rstd * g[i][j] + b[i][j];
-    row_store<V>(r, out + (int64_t)row * H, lane);
-}
-
 template <int V>
 __global__ __launch_bounds__(256) void adaln_gate_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ y,
@@ -308,21 +256,6 @@ extern "C" int e3d_residual_layernorm_drop_fwd(const float* x, const float* resi
     DISPATCH_V(H, hipLaunchKernelGGL((residual_layernorm_kernel<V, true>), grid, block, 0, (hipStream_t)stream, x, residual, gamma,
                                      beta, eps, s_out, out, M, d));
     return e3d_launch_status("e3d_residual_layernorm_drop_fwd");
-}
-
-extern "C" int e3d_row_stats_f32(const float* z, float eps, float* stats, int M, int H, void* stream) {
-    E3D_REQUIRE(z && stats && M > 0, "row_stats: bad arguments");
-    const dim3 grid((M + 3) / 4), block(256);
-    DISPATCH_V(H, hipLaunchKernelGGL(row_stats_kernel<V>, grid, block, 0, (hipStream_t)stream, z, eps, stats, M));
-    return e3d_launch_status("e3d_row_stats_f32");
-}
-
-extern "C" int e3d_layernorm_from_stats_f32(const float* z, const float* stats, const float* gamma, const float* beta, float* out,
-                                            int M, int H, void* stream) {
-    E3D_REQUIRE(z && stats && gamma && beta && out && M > 0, "layernorm_from_stats: bad arguments");
-    const dim3 grid((M + 3) / 4), block(256);
-    DISPATCH_V(H, hipLaunchKernelGGL(apply_stats_kernel<V>, grid, block, 0, (hipStream_t)stream, z, stats, gamma, beta, out, M));
-    return e3d_launch_status("e3d_layernorm_from_stats_f32");
 }
 
 extern "C" int e3d_adaln_gate_fwd(const float* x, const float* y, const float* mod, int branch,

@@ -47,18 +47,12 @@ _SIGNATURES = {
     "e3d_gemm_wgrad_grouped_f32_split": (c_int, [_P, _P, _P, _P, c_uint64, c_int, c_int64, c_int64, c_int, c_int, c_int, c_int, _P]),
     "e3d_residual_layernorm_drop_fwd": (c_int, [_P, _P, _P, _P, c_float, _P, _P, c_int, c_int, c_float, c_uint64, _P]),
     "e3d_layernorm_bwd_drop": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P]),
-    # deferred LayerNorm (inference, large M)
-    "e3d_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_int64]),
-    "e3d_gemm_bias_act_f32_split_ln": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, c_float,
-                                               _P, _P, c_int64, _P, _P, _P, _P]),
     # row-complete GEMM + bias + residual + LayerNorm (ABI v4)
     "e3d_weight_planes_bytes": (c_int64, [c_int, c_int]),
     "e3d_weight_planes_f32_split": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "e3d_gemm_residual_layernorm_supported": (c_int, [c_int, c_int, c_int, c_int64]),
     "e3d_gemm_residual_layernorm_f32_split": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, _P, c_float, _P, c_int64,
                                                       c_int, c_int, c_int, c_int, c_float, _P]),
-    "e3d_row_stats_f32": (c_int, [_P, c_float, _P, c_int, c_int, _P]),
-    "e3d_layernorm_from_stats_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "e3d_gemm_wgrad_ragged_f32_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_uint64, c_int, c_int, c_int, _P]),
     "e3d_relkey_attn_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "e3d_relkey_attn_bwd": (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P,

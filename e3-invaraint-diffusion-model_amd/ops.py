@@ -297,66 +297,6 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None, p
     return out
 
 
-# ----------------------------------------------------------------------------- deferred LayerNorm (inference, large M)
-def row_stats(z, eps):
-    """(mean, rstd) per row of z [M, H] -> [M, 2] (two-pass, as the LayerNorm kernels compute them)."""
-    _chk(z, "row_stats.z")
-    assert z.is_contiguous() and z.dim() == 2
-    stats = torch.empty((z.shape[0], 2), device=z.device, dtype=torch.float32)
-    hip.check(hip.lib().e3d_row_stats_f32(_p(z), float(eps), _p(stats), z.shape[0], z.shape[1], _stream()), "e3d_row_stats_f32")
-    return stats
-
-
-def layernorm_from_stats(z, stats, gamma, beta):
-    out = torch.empty_like(z)
-    hip.check(hip.lib().e3d_layernorm_from_stats_f32(_p(z), _p(stats), _p(gamma), _p(beta), _p(out), z.shape[0], z.shape[1],
-                                                     _stream()), "e3d_layernorm_from_stats_f32")
-    return out
-
-
-def folded_linear(weight, bias, gamma, beta):
-    """(W * gamma, b + W beta): LayerNorm's affine part folded into the linear layer that consumes it, so that the
-    consumer GEMM only has to centre and scale the rows of the pre-norm sum it reads.  Cached on the weight (inference),
-    keyed like every derived-weight cache."""
-    key = weight_key(weight, bias, gamma, beta) if bias is not None else weight_key(weight, gamma, beta)
-    ent = getattr(weight, "_e3d_folded", None)
-    if ent is not None and ent[0] == key:
-        return ent[1], ent[2]
-    with torch.no_grad():
-        w = (weight.detach() * gamma.detach()[None, :]).contiguous()
-        b = torch.mv(weight.detach().double(), beta.detach().double()).float()
-        if bias is not None:
-            b = b + bias.detach()
-    try:
-        weight._e3d_folded = (key, w, b)
-    except AttributeError:
-        pass
-    return w, b
-
-
-def gemm_ln_supported(M, N, K, a):
-    terms = GEMM_MODES[GEMM_MODE]
-    return terms in (3, 19) and a.stride(1) == 1 and bool(hip.lib().e3d_gemm_ln_supported(M, N, K, a.stride(0)))
-
-
-def gemm_ln(a, weight, bias, act=ACT_NONE, absmax=None, a_stats=None, res=None, res_stats=None, res_gamma=None, res_beta=None):
-    """The persistent split GEMM with a deferred LayerNorm on its input rows (``a_stats``: consumer) or as its residual
-    (``res`` = z_prev with ``res_stats`` / ``res_gamma`` / ``res_beta``: producer) -- include/e3d_hip.h."""
-    M, K = a.shape
-    N = weight.shape[0]
-    out = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    terms = GEMM_MODES[GEMM_MODE]
-    scale = 1.0
-    if terms == 19:
-        weight, scale = f16_weight(weight)
-    with _timed("gemm", (M, N, K, act)):
-        hip.check(hip.lib().e3d_gemm_bias_act_f32_split_ln(
-            _p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), M, N, K, act, terms, _p(absmax), scale, _p(a_stats),
-            _p(res), res.stride(0) if res is not None else 0, _p(res_stats), _p(res_gamma), _p(res_beta), _stream()),
-            "e3d_gemm_bias_act_f32_split_ln")
-    return out
-
-
 class arithmetic:
     """``with ops.arithmetic("bf16x6"):`` -- GEMM and attention arithmetic for the enclosed calls (entry points use it
     to mirror the precision the reference runs that script at; E3D_GEMM_MODE / E3D_ATTN_MODE in the environment

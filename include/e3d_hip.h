@@ -398,27 +398,6 @@ int e3d_residual_layernorm_drop_fwd(const float* x, const float* residual, const
 int e3d_layernorm_bwd_drop(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
                            float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, void* stream);
 
-/* ---- deferred LayerNorm (ABI v3; inference at large M) ------------------------------------------------------------------
- * BertSelfOutput / BertOutput compute LayerNorm(dense(x) + residual) (transformers 4.38.2 modeling_bert.py; the reference
- * runs them through structure_model/model.py:180-215): at M = 65536 rows that LayerNorm is a 600-MB pass of its own after
- * every N = 768 GEMM.  Here the hidden state between two blocks is kept as its PRE-norm sum z plus per-row (mean, rstd)
- * (e3d_row_stats_f32: the same two-pass statistics) and the normalised tensor is never written:
- *   consumer (a_stats != NULL): out = act(LayerNorm(A) W^T + b) where A is such a z -- every A element becomes
- *     (a - mean) * rstd while it is staged; the caller folds gamma into the weight (W * gamma along K) and beta into the
- *     bias (b + W beta): ops.folded_linear is the pattern;
- *   producer (res != NULL): out = A W^T + b + LayerNorm(res) with the residual rebuilt in the epilogue from res (= z_prev,
- *     row stride ldr), its row constants res_stats and the column's res_gamma / res_beta; out is the next pre-norm sum.
- * Shapes the persistent 256x256 kernel takes only (e3d_gemm_ln_supported); terms 3 or 19.
- * e3d_layernorm_from_stats_f32 materialises (z - mean) * rstd * gamma + beta where a consumer outside this path needs it. */
-int e3d_gemm_ln_supported(int M, int N, int K, int64_t lda);
-int e3d_gemm_bias_act_f32_split_ln(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc,
-                                   int M, int N, int K, int act, int terms, float* out_absmax, float out_scale,
-                                   const float* a_stats, const float* res, int64_t ldr, const float* res_stats,
-                                   const float* res_gamma, const float* res_beta, void* stream);
-int e3d_row_stats_f32(const float* z, float eps, float* stats, int M, int H, void* stream);
-int e3d_layernorm_from_stats_f32(const float* z, const float* stats, const float* gamma, const float* beta, float* out, int M,
-                                 int H, void* stream);
-
 /* ---- row-complete GEMM + bias + residual + LayerNorm (ABI v4; inference at large M) ----------------------------------
  * BertSelfOutput / BertOutput whole -- LayerNorm(dense(x) + residual), transformers 4.38.2 modeling_bert.py, reached through
  * structure_model/model.py:197-213 and sequence_model/model.py:226-231 -- as ONE launch whose workgroups own whole 768-wide
