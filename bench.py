@@ -387,6 +387,12 @@ def main():
     dom_flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in dom) / max(1, len(dom))
     dom_bytes = sum(4.0 * (m[0] * m[2] + m[1] * m[2] + m[0] * m[1] + m[1]) for _, m in dom) / max(1, len(dom))
 
+    # the row-complete GEMM + bias + residual + LayerNorm launches (csrc/gemm_rowln.hip; BertSelfOutput / BertOutput)
+    rowln = [(ev0.elapsed_time(ev1), m) for n, ev0, ev1, m in trace if n == "gemm_layernorm"]
+    rowln_ms = sum(t for t, _ in rowln) / max(1, len(rowln)) or float("nan")
+    rowln_flops = sum(2.0 * m[0] * m[1] * m[2] for _, m in rowln) / max(1, len(rowln))
+    rowln_bytes = sum(4.0 * (m[0] * m[2] + m[1] * m[2] + 2 * m[0] * m[1] + 3 * m[1]) for _, m in rowln) / max(1, len(rowln))
+
     if rank == 0:
         traffic = gemm_traffic = traffic_source = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
@@ -464,6 +470,17 @@ def main():
                          "peak_note": "fp32 MFMA 157.3 for f32; bf16 dense 2500 / terms for the split modes; traffic = HBM "
                                       "bytes per launch (average over the same launches) from the PMC passes in "
                                       "profiles/traffic.json"},
+            # BertSelfOutput / BertOutput as one launch each (round 4): 2MNK flops; A + weight planes + residual in, out
+            # written once -- the GEMM + LayerNorm pair it replaces moves one more [M, 768] tensor out and two more in
+            "roofline_gemm_layernorm": {
+                "kernel": "gemm_rowln_kernel (e3d_gemm_residual_layernorm_f32_split): dense -> + bias + residual -> LayerNorm, "
+                          f"all {len(rowln)} launches of one step",
+                "bound": "mfma", "achieved": rowln_flops / (rowln_ms * 1e-3) / 1e12, "peak": gemm_peak, "unit": "TFLOP/s",
+                "frac": rowln_flops / (rowln_ms * 1e-3) / 1e12 / gemm_peak, "avg_launch_ms": rowln_ms,
+                "launches_per_step": len(rowln), "algorithmic_flops_per_launch": rowln_flops,
+                "algorithmic_bytes_per_launch": rowln_bytes,
+                "hbm_algorithmic_GBps": rowln_bytes / (rowln_ms * 1e-3) / 1e9 if rowln else None,
+                "replaces": "gemm_split256p_kernel<ACT_NONE> + residual_layernorm_kernel (E3D_GEMM_ROWLN=0 runs that pair)"},
             "gemm_shapes": shapes,
             "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",
                               "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
