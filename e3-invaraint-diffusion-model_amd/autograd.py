@@ -46,9 +46,43 @@ class deferred_weight_grads:
     # and computed, backward continues with an empty queue).  E3D_DEFER_WGRAD_MAX_GB, default 16 (of 288 GB of HBM).
     MAX_BYTES = int(float(os.environ.get("E3D_DEFER_WGRAD_MAX_GB", "16")) * 2 ** 30)
 
-    def __init__(self, on_param=None, stages=3):
+    # OPT-IN (E3D_WGRAD_OVERLAP=1), measured and not kept as the default: in a single process every
+    # OVERLAP_CHUNK queued layers can be computed at once on a SIDE stream while backward carries on with the input-gradient
+    # chain of the earlier layers on the caller's stream (a slice needs nothing but its saved (dz, x); the streams join before
+    # the last slice, i.e. before the optimizer; a captured step keeps the fork / join as graph dependencies; every problem
+    # of a grouped launch is a whole reduction, so the gradients are bit-identical to the serial order -- tested).  The
+    # idea was to fill the quarter of the chip the M = 4096 input-gradient launches leave idle.  Measured on MI355X, graph
+    # replay, same box: structure 24.9 -> 25.3 ms, sequence 19.7 -> 19.6 ms (profiles/r04_train_wgrad_overlap_ab.log): a
+    # 512-thread weight-gradient workgroup (96 KB of LDS) and an input-gradient workgroup (84 KB) cannot share a CU, so the
+    # two streams take turns on the CUs instead of overlapping, and the chain on the caller's stream is what gets delayed.
+    OVERLAP = os.environ.get("E3D_WGRAD_OVERLAP", "0") == "1"
+    OVERLAP_CHUNK = int(os.environ.get("E3D_WGRAD_CHUNK", "24"))
+    _SIDE = {}
+
+    def __init__(self, on_param=None, stages=3, overlap=None):
         self.pending, self.on_param, self.stages = [], on_param, max(1, int(stages))
         self.queued_bytes, self.early_flushes, self._seen_ptrs, self._early_touched = 0, 0, set(), {}
+        self.overlap = (self.OVERLAP if overlap is None else bool(overlap)) and on_param is None
+        self.side_flushes, self._side, self.queued_total = 0, None, 0
+
+    def _flush_on_side_stream(self, items):
+        dev = items[0][0].device
+        main = torch.cuda.current_stream(dev)
+        side = self._SIDE.get(dev.index)
+        if side is None:
+            side = self._SIDE[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                     # the slice's dz / x were written on the caller's stream
+        with torch.cuda.stream(side):
+            touched = self._flush_slice(items)
+        for dz, x, _, _ in items:                  # freed by the caller's stream while the side stream may still read them
+            dz.record_stream(side)
+            if x is not None:
+                x.record_stream(side)
+        for p_ in touched.values():                # allocated on the side stream, consumed by the optimizer on the caller's
+            if p_.grad is not None:
+                p_.grad.record_stream(main)
+        self._side, self.side_flushes = side, self.side_flushes + 1
+        return touched
 
     def __enter__(self):
         assert deferred_weight_grads.active is None, "deferred_weight_grads blocks do not nest"
@@ -63,6 +97,7 @@ class deferred_weight_grads:
 
     def add(self, dz, x, weight, bias):
         self.pending.append((dz, x, weight, bias))
+        self.queued_total += 1
         for t in (dz, x):      # (the row blocks of a packed weight share one dz / x: count a storage once)
             if t is None:
                 continue
@@ -70,6 +105,11 @@ class deferred_weight_grads:
             if key not in self._seen_ptrs:
                 self._seen_ptrs.add(key)
                 self.queued_bytes += t.untyped_storage().nbytes()
+        if self.overlap and dz.is_cuda and len(self.pending) >= self.OVERLAP_CHUNK:
+            pending, self.pending = self.pending, []
+            self.queued_bytes, self._seen_ptrs = 0, set()
+            self._flush_on_side_stream(pending)
+            return
         if self.queued_bytes > self.MAX_BYTES:
             # early flush: compute what is queued, but report nothing to a listening averager yet -- a weight used
             # twice in the forward pass (sequence model: ligand_feature_emb) may still receive its second contribution
@@ -103,6 +143,9 @@ class deferred_weight_grads:
     def flush(self):
         pending, self.pending = self.pending, []
         self.queued_bytes, self._seen_ptrs = 0, set()
+        if self._side is not None:                 # join: the last slice (and the optimizer) follow every earlier one
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            self._side = None
         early, self._early_touched = self._early_touched, {}
         if self.on_param is not None:     # parameters finished by an early flush and not queued again: complete now
             still = {id(t) for item in pending for t in item[2:] if t is not None}

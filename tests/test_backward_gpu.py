@@ -310,7 +310,7 @@ def _grad_compare(model, sd, loss_dev, loss_ref_fn, tol, defer=False):
         staged = defer == "staged"         # as under a gradient averager: flushed in 3 slices, parameters reported
         with deferred_weight_grads(on_param=reported.append if staged else None, stages=3) as q:
             loss_dev.backward()
-            n_queued = len(q.pending)
+            n_queued = q.queued_total      # (single process: slices of 24 layers already left on the side stream)
             assert n_queued > 10           # the linear layers really took the deferred path
         if staged:
             ids = [id(p) for p in reported]
