@@ -265,13 +265,16 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
             ef[kb][1] = pj[256 + kb * 64];
         }
     };
+    auto dot_q_acc = [&](const bf16x8 (&x)[4][2], f32x16 acc) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = mfma3(x[kb], qf[kb], acc);
+        return acc;
+    };
     auto dot_q = [&](const bf16x8 (&x)[4][2]) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) acc = mfma3(x[kb], qf[kb], acc);
-        return acc;
+        return dot_q_acc(x, acc);
     };
 
     stage_load(Set0{}, 0);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;      // (m_run: placeholder until the first tile sets it)
     // Ring addressing without per-tile integer math.  Tiles alternate PAR = 0 / 1 (ring rotation 0 / 32 rows, LDS
     // buffer 0 / 1).  With rho = mfma32_row(r, half) = rp(r) + 4 half, rp(r) = (r & 3) + 8 (r >> 2) <= 27:
     //   T^T row rho is written to ring row rho + rot:      ring_w[(rot + rp) * RING_LD]           (immediates)
@@ -352,7 +355,24 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
         ASTAMP(0);                                //  hipcc then counts vmcnt exactly instead of draining to 0)
         ASTAMP(1);
 
+        // The accumulator of S^T = K Q^T starts from everything that is ADDED to the scores -- the additive key bias, the
+        // rel-key term (this tile's T^T block, written to the ring at the end of the previous tile or by the prologue, so the
+        // write -> read round trip of the skew is off the critical path) and minus the running maximum -- so the scores
+        // leave the MFMAs relative to the running maximum, ready for v_exp_f32: 16 + 16 additions in front of the MFMAs
+        // instead of 16 + 16 + 16 behind them (round 4; the instruction counts are in profiles/r04_attn_coop_pmc_insts_*)
+        const float* kbias = reinterpret_cast<const float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B);
         f32x16 s;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(kbias + 8 * g + 4 * half);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[4 * g + j] = bv[j] - m_run;     // scores are in log2 units / sqrt(d) (Q_SCALE)
+        }
+        if (RELKEY) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s[r] += PAR ? ring[rd_odd[r]] : ring_e[(27 - ((r & 3) + 8 * (r >> 2))) * RING_LD];
+        }
         {   // S^T = K Q^T
             bf16x8 kf[4][2];
             const unsigned char* kr = buf + qi * K_ROW_B + 16 * half;
@@ -361,49 +381,35 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
                 kf[kb][0] = *reinterpret_cast<const bf16x8*>(kr + 32 * kb);
                 kf[kb][1] = *reinterpret_cast<const bf16x8*>(kr + K_PLANE_B + 32 * kb);
             }
-            s = dot_q(kf);
+            s = dot_q_acc(kf, s);
         }
         ASTAMP(2);
-        if (RELKEY) {
-            // rel-key term: the T^T block of this tile was written to the ring at the end of the previous tile (or by
-            // the prologue), so the write -> read round trip of the skew is off the critical path
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                s[r] += PAR ? ring[rd_odd[r]] : ring_e[(27 - ((r & 3) + 8 * (r >> 2))) * RING_LD];
-        }
         // K/V of tile t+2 into the set whose tile-t data was stored a tile ago (clamped re-loads at the end)
         const int kt_ld = DEEP ? (kt + 2 < k_tiles ? kt + 2 : k_tiles - 1) : kt_next;
         if (PAR == 0) stage_load(Set0{}, kt_ld * 32);
         else stage_load(Set1{}, kt_ld * 32);
         ASTAMP(3);
 
-        const float* kbias = reinterpret_cast<const float*>(buf + 2 * K_PLANE_B + 2 * V_PLANE_B);
-        float tmax = -INFINITY;
+        float tmax = -INFINITY;     // the tile's largest score RELATIVE to the running maximum
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(kbias + 8 * g + 4 * half);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[4 * g + j] += bv[j];              // scores are already in log2 units / sqrt(d) (Q_SCALE)
-                tmax = fmaxf(tmax, s[4 * g + j]);
-            }
-        }
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        // deferred rescale: only when some query of the tile outgrows its running maximum by more than 2^TAU
-        // (always on the first tile: m_run = -inf).  Wave-uniform branch; the lanes that do not need it get alpha = 1.
-        const bool grow = tmax > m_run + rescale_tau;
+        // deferred rescale: only when some query of the tile outgrows its running maximum by more than 2^TAU -- and always
+        // on the first tile, whose "running maximum" is the placeholder 0.  Wave-uniform branch; the lanes that do not need
+        // it move by 0 (alpha = 1).
+        const bool grow = kt == 0 || tmax > rescale_tau;
         if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
-            const float m_new = grow ? tmax : m_run;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-            m_run = m_new;
+            const float delta = grow ? tmax : 0.f;
+            const float alpha = kt == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);   // (first tile: O = l = 0 anyway)
+            m_run += delta;
             l_run *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; s[r] -= delta; }
         }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run);
+            s[r] = __builtin_amdgcn_exp2f(s[r]);
             psum += s[r];
         }
         l_run += psum;
