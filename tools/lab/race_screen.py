@@ -127,5 +127,38 @@ for (N, K, M, count) in ((768, 768, 4096, 12), (2304, 768, 4096, 4), (1024, 768,
                 bad += 1
                 print(f"grouped wgrad {N}x{K} over {M} rep {r} problem {p_}: block error {err:.2e}", flush=True)
     print(f"grouped wgrad dW[{N}x{K}] over {M} tokens x {count}: worst block error vs fp64 {worst:.2e}", flush=True)
+# round 4: the row-complete GEMM + bias + residual + LayerNorm launch (LDS-DMA staging with counted vmcnt waits, wave-private
+# W buffers refilled without a barrier, three A buffers behind one barrier per k32 pair, residual ring, permlane / DPP row
+# sums): many launches on fresh data while a second stream keeps the CUs and HBM busy (uneven load is where a missing wait
+# shows), every 32 x 32 block against the unfused pair, run-to-run bit identity (no atomics in that kernel)
+ops.ROWLN_MIN_M = 1
+side = torch.cuda.Stream()
+big_a, big_w = torch.randn(32768, 768, device=dev), torch.randn(2304, 768, device=dev) / 27.7
+for (M, K) in ((65536, 768), (65536, 1024), (16384, 768), (8352, 1024), (4096, 64), (224, 768)):
+    H, worst = 768, 0.0
+    for r in range(reps):
+        g = torch.Generator(device=dev).manual_seed(517 * r + M % 911 + K)
+        a = torch.randn(M, K, device=dev, generator=g)
+        w = (torch.randn(H, K, device=dev, generator=g) / K ** 0.5).contiguous()
+        b, res = torch.randn(H, device=dev, generator=g), torch.randn(M, H, device=dev, generator=g)
+        gamma, beta = torch.rand(H, device=dev, generator=g) + 0.5, torch.randn(H, device=dev, generator=g)
+        with torch.no_grad():
+            pair = ops.residual_layernorm(ops.gemm(a, w, b, mode="f16x3"), res, gamma, beta, 1e-12)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    ops.gemm(big_a, big_w, None, mode="bf16x3")
+            out = ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode="f16x3")
+            again = ops.linear_residual_layernorm(a, w, b, res, gamma, beta, 1e-12, mode="f16x3")
+        torch.cuda.synchronize()
+        if not torch.equal(out, again):
+            bad += 1
+            print(f"rowln {M}x768x{K} rep {r}: NOT bit-identical between two launches", flush=True)
+        err = ((out - pair).abs().view(M // 32, 32, H // 32, 32).amax((1, 3)) / pair.abs().max()).max().item()
+        worst = max(worst, err)
+        if err > 2e-6 or not bool(torch.isfinite(out).all()):
+            bad += 1
+            print(f"rowln {M}x768x{K} rep {r}: block error vs the unfused pair {err:.2e}", flush=True)
+    print(f"rowln {M}x768x{K}: {reps} launches under load, worst block difference from the unfused pair {worst:.2e}", flush=True)
 print("race screen:", "CLEAN" if bad == 0 else f"{bad} PROBLEMS")
 sys.exit(1 if bad else 0)
