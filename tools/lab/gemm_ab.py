@@ -13,6 +13,7 @@ import __graft_entry__  # noqa: E402
 
 pkg = __graft_entry__.load_package()
 ops, lib = pkg.ops, pkg.hip.lib()
+MODE = os.environ.get("GEMM_AB_MODE", "bf16x3")
 forms = [int(x) for x in sys.argv[1:]] or [4, 3]
 DEV = "cuda:0"
 shapes = [(65536, 768, 768, 0), (65536, 2304, 768, 0), (65536, 1024, 768, 1), (65536, 768, 1024, 0), (65536, 1536, 768, 0),
@@ -24,7 +25,7 @@ for M, N, K, act in shapes:
     outs = {}
     for f in forms:
         lib.e3d_gemm_kernel_select(f)
-        outs[f] = ops.gemm(a, w, b, act, mode="bf16x3").clone()
+        outs[f] = ops.gemm(a, w, b, act, mode=MODE).clone()
     ref = outs[forms[0]]
     same = {f: bool(torch.equal(outs[f], ref)) for f in forms}
     ref64 = (a[:256].double() @ w.double().t() + b.double())
@@ -36,10 +37,10 @@ for M, N, K, act in shapes:
         for f in forms:
             lib.e3d_gemm_kernel_select(f)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ops.gemm(a, w, b, act, mode="bf16x3")
+            ops.gemm(a, w, b, act, mode=MODE)
             e0.record()
             for _ in range(10):
-                ops.gemm(a, w, b, act, mode="bf16x3")
+                ops.gemm(a, w, b, act, mode=MODE)
             e1.record()
             torch.cuda.synchronize()
             times[f].append(e0.elapsed_time(e1) / 10)
