@@ -38,6 +38,10 @@ print(f"workgroups (us, s_memrealtime): start min/med/max {starts[0]:.1f}/{start
 byx = [[] for _ in range(8)]
 for i in range(256):
     byx[i % 8].append((wg[4 * i + 2] - wg[4 * i]) / 100.0)
+byp = [[] for _ in range(4)]
+for i in range(256):
+    byp[(i >> 3) & 3].append((wg[4 * i + 2] - wg[4 * i]) / 100.0)
+print("duration by tile-order pattern (blockIdx >> 3) & 3 (min / median / max us): " + "  ".join(f"{min(v):.1f}/{sorted(v)[len(v) // 2]:.1f}/{max(v):.1f}" for v in byp))
 print("duration by blockIdx % 8 (median us): " + " ".join(f"{sorted(v)[len(v) // 2]:.1f}" for v in byx))
 # the step stamps hold the LAST tile of the workgroup that wrote them (64 rows: NM = 2): print tile-level first
 names = ["tile top", "loads landed + barrier", "k loop done", "residual done", "stats done", "stores issued", "stores retired"]
