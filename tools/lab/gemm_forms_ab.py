@@ -15,7 +15,8 @@ ops, lib = pkg.ops, pkg.hip.lib()
 from e3diff_amd import autograd as AG  # noqa: E402
 
 DEV = "cuda:0"
-forms = [0, 1, 2, 3]
+forms = [int(x) for x in os.environ.get("FORMS", "0,1,2,3,4").split(",")]   # 4 = three-tile ring (gemm_ring3_kernel)
+MS = [int(x) for x in os.environ.get("MS", "64,256,1024,2048,4096,8192").split(",")]
 
 
 def bench(fn):
@@ -41,15 +42,15 @@ def bench(fn):
 
 
 for mode in ("bf16x3",):
-    for M in (64, 256, 1024, 2048, 4096, 8192):
-        for N, K in ((768, 768), (2304, 768), (768, 1024)):
+    for M in MS:
+        for N, K in ((768, 768), (2304, 768), (768, 1024), (1024, 768)):
             a = torch.randn(M, K, device=DEV)
             w = torch.randn(N, K, device=DEV) / K ** 0.5
             b = torch.randn(N, device=DEV)
             t, same = bench(lambda: ops.gemm(a, w, b, mode=mode))
             fl = 2.0 * M * N * K
             print(f"fwd {mode} M={M:5d} N={N:4d} K={K:4d}: " + "  ".join(f"form {f}: {t[f] * 1e3:6.1f} us {fl / t[f] / 1e9:6.1f} TF" for f in forms) + f"  same={same}", flush=True)
-    for M, N, K in ((4096, 768, 768), (8192, 768, 768), (4096, 2304, 768), (4096, 1024, 768)):   # dW[N,K] = dz[M,N]^T x[M,K]
+    for M, N, K in (() if os.environ.get("SKIP_WGRAD") else ((4096, 768, 768), (8192, 768, 768), (4096, 2304, 768), (4096, 1024, 768))):   # dW[N,K] = dz[M,N]^T x[M,K]
         dz = torch.randn(M, N, device=DEV)
         x = torch.randn(M, K, device=DEV)
         t, same = bench(lambda: AG.gemm_general(dz, True, x, True, N, K, M, mode=mode))
