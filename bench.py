@@ -441,7 +441,7 @@ def main():
             # peak) and HBM time (algorithmic bytes / 8 TB/s) is larger; frac = that time / measured time
             "roofline_attention": (lambda t_mfma, t_hbm: {
                 "kernel": ("attn_fwd_kernel<relkey> (e3d_relkey_attn_fwd)" if args.gemm_mode == "f32" else
-                           f"attn_coop_kernel<8 waves, relkey> for bf16x3 / f16x3, attn_fwd_split_kernel / attn_fwd_kernel otherwise (e3d_relkey_attn_fwd_split, {args.gemm_mode})"),
+                           f"attn_coop_kernel<4 waves, relkey> for bf16x3 / f16x3, attn_fwd_split_kernel / attn_fwd_kernel otherwise (e3d_relkey_attn_fwd_split, {args.gemm_mode})"),
                 "bound": "hbm" if t_hbm > t_mfma else "mfma",
                 "achieved": a_gb if t_hbm > t_mfma else a_tf,
                 "peak": PEAK_HBM_GBPS if t_hbm > t_mfma else gemm_peak,

@@ -15,7 +15,7 @@ ops, lib = pkg.ops, pkg.hip.lib()
 from e3diff_amd import autograd as AG  # noqa: E402
 
 DEV = "cuda:0"
-forms = [int(x) for x in os.environ.get("FORMS", "0,1,2,3,4").split(",")]   # 4 = three-tile ring (gemm_ring3_kernel)
+forms = [int(x) for x in os.environ.get("FORMS", "0,1,2,3").split(",")]
 MS = [int(x) for x in os.environ.get("MS", "64,256,1024,2048,4096,8192").split(",")]
 
 

@@ -38,7 +38,7 @@ def dump(rows, name):
 
 
 GEMM = ("gemm_split256p_kernel<0", "gemm_split256p_kernelILi0E")   # <ACT_NONE, element type>, demangled / mangled
-ATTN = ("attn_coop_kernel<8, true", "attn_coop_kernelILi8ELb1E")
+ATTN = ("attn_coop_kernel<4, true", "attn_coop_kernelILi4ELb1E")   # 4-wave workgroups since round 4 (8-wave: E3D_ATTN_W=8)
 af, aw = counter_rows(f"{O}/pmc_fetch/a_counter_collection.csv", ATTN), \
     counter_rows(f"{O}/pmc_write/a_counter_collection.csv", ATTN)
 gf, gw = counter_rows(f"{O}/pmc_gfetch/g_counter_collection.csv", GEMM), counter_rows(f"{O}/pmc_gwrite/g_counter_collection.csv", GEMM)
@@ -51,7 +51,7 @@ traffic = {
     "_detail": {
         "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes: FETCH_SIZE / WRITE_SIZE in KiB from separate rocprofv3 --pmc passes "
                    "(no trace domains); x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section)",
-        "attn": {"kernel": "attn_coop_kernel<8 waves, rel-key, default arithmetic>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
+        "attn": {"kernel": "attn_coop_kernel<4 waves, rel-key, default arithmetic>, tools/bench_kernels.py attn_pmc", "FETCH_SIZE_KiB_raw_avg": afm,
                  "WRITE_SIZE_KiB_avg": awm, "algorithmic_bytes": (4 * L * H * 4 + (2 * L - 1) * 256 + 4 * L) * B},
         "gemm": {"kernel": f"{GEMM[0]}, ...>: every launch of one bench.py --headline-only step ({ng} dispatches incl. the untimed "
                            "trace pass)", "FETCH_SIZE_KiB_raw_avg": gfm, "WRITE_SIZE_KiB_avg": gwm},
