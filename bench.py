@@ -295,6 +295,14 @@ def main():
         # i.e. every flop the reference does.
         pkg.ops.set_gemm_mode(args.gemm_mode)
         pkg.ops.set_attn_mode(args.gemm_mode)
+        # THE HEADLINE FIRST (round 4): W untimed + K timed steps of the dense sweep, before any of the extras below touches
+        # the card.  The extras take about a minute of full load, and a card that has been busy that long holds a 3-5 %
+        # lower clock (DVFS); the same K steps are timed AGAIN after them and reported beside the headline as
+        # ``ms_per_step_after_extras`` (what a long chain sustains), never as ``value``.
+        lib.e3d_attn_skip_padded_tiles(0)
+        timed(full_step, args.warmup)
+        elapsed = timed(full_step, args.steps)
+        by_mode[args.gemm_mode] = elapsed / args.steps
         lib.e3d_attn_skip_padded_tiles(1)
         elapsed_skip = float("nan")
         if not args.headline_only:
@@ -311,9 +319,6 @@ def main():
                     by_mode[mode] = timed(full_step, max(1, args.steps // 2)) / max(1, args.steps // 2)
         pkg.ops.set_gemm_mode(args.gemm_mode)
         pkg.ops.set_attn_mode(args.gemm_mode)
-        timed(full_step, args.warmup)
-        elapsed = timed(full_step, args.steps)
-        by_mode[args.gemm_mode] = elapsed / args.steps
         # the sampler's actual loop: receptor encoded once, padding skip on (product defaults)
         lib.e3d_attn_skip_padded_tiles(1)
         cache = model.encode_receptor(pk["receptor_seq"], pk["receptor_angles"], pk["receptor_attn_mask"])
@@ -345,8 +350,13 @@ def main():
                 elapsed_trimmed = time.perf_counter() - t0
             del cache_t
 
-        # per-launch durations of the named kernels (HIP events on the launch stream), one dense step
+        # the headline loop once more, on the card as the extras left it (hot)
         lib.e3d_attn_skip_padded_tiles(0)
+        elapsed_after = float("nan")
+        if not args.headline_only:
+            timed(full_step, 1)
+            elapsed_after = timed(full_step, args.steps)
+        # per-launch durations of the named kernels (HIP events on the launch stream), one dense step
         pkg.ops.TRACE = []
         full_step(500, x, nxt)
         torch.cuda.synchronize()
@@ -356,10 +366,10 @@ def main():
 
     modes = sorted(by_mode)
     if dist is not None:
-        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed] + [by_mode[m] for m in modes],
+        t = torch.tensor([elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed, elapsed_after] + [by_mode[m] for m in modes],
                          device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed, *rest = t.tolist()
+        elapsed, elapsed_cached, elapsed_skip, elapsed_trimmed, elapsed_after, *rest = t.tolist()
         by_mode = dict(zip(modes, rest))
 
     def avg_ms(name):
@@ -410,6 +420,9 @@ def main():
             "unit": "pocket-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_after_extras": None if (args.headline_only or elapsed_after != elapsed_after) else 1e3 * elapsed_after / args.steps,
+            "ms_per_step_note": "ms_per_step / value: the W + K steps run FIRST in the process; ms_per_step_after_extras: the same K steps "
+                                "timed again after the other legs of this command (~1 min of full load: the card then holds a lower clock)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 storage and accumulation, bf16x3 products",
                       "bf16x6": "f32 storage and accumulation, bf16x6 products (fp32 grade)",

@@ -361,6 +361,7 @@ class _WtEntry:
 
 
 _WT_REGISTRY = {}     # ids of the parameters behind a weight -> _WtEntry
+_WT_RETIRED = []     # entries dropped from the registry while a captured graph may still use their buffers
 
 
 def _refresh_transposes(entries):
@@ -398,7 +399,16 @@ def forget_transposes(keep):
     for key in list(_WT_REGISTRY):
         ps = _WT_REGISTRY[key].parts()
         if ps is None or not all(id(p) in keep for p in ps):
-            del _WT_REGISTRY[key]
+            # parked, not freed: another model's GraphedStep may still be alive, and its graph baked both the
+            # refresh launches that WRITE this buffer and the input-gradient GEMMs that READ it -- as long as the buffer
+            # stays allocated that graph remains self-consistent; returned to the allocator it would be written into memory
+            # someone else owns.  (As ops._SKINNY_RETIRED; release_retired_transposes() frees them when no graph is left.)
+            _WT_RETIRED.append(_WT_REGISTRY.pop(key))
+
+
+def release_retired_transposes():
+    """Free the W^T buffers forget_transposes parked (call when no captured training step of another model is alive)."""
+    _WT_RETIRED.clear()
 
 
 def _transposed_weight(weight):

@@ -210,8 +210,13 @@ def f16_weight(weight):
     key = weight_key(weight)
     if ent is not None and ent[0] == key:
         return ent[1], ent[2]
-    if torch.cuda.is_current_stream_capturing():     # no host read-back inside a capture (callers warm up first)
-        return weight, 1.0
+    if torch.cuda.is_current_stream_capturing():
+        # no host read-back inside a capture, and no silent fallback either: a graph captured with the raw
+        # weight would run f16x3 on un-pre-scaled weights at every replay.  The capturers (GraphedReverseStep,
+        # GraphedDenoiseStep) run their body eagerly first, which fills this cache; their except-paths fall back to eager
+        # launches if this is ever raised.
+        raise RuntimeError("f16x3: the pre-scaled copy of a weight is missing inside a stream capture -- run the step eagerly once "
+                           "before capturing it (building the copy reads max |w| back to the host)")
     with torch.no_grad():
         amax = float(weight.detach().abs().max())
         if not math.isfinite(amax) or amax == 0.0:

@@ -144,9 +144,15 @@ class GraphedDenoiseStep:
         self.out = None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        # the warm-up draws uniforms when the chain samples (diverse, no injected u): put the device generator back
+        # afterwards, so that a seeded chain sees the same random numbers whether its steps are replayed or launched one
+        # by one (which path runs is decided by a size threshold)
+        rng = torch.cuda.get_rng_state(dev)
         with torch.cuda.stream(side):       # warm-up off the capture: first-launch attribute calls, caches, allocator
             self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        torch.cuda.set_rng_state(rng, dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._body()

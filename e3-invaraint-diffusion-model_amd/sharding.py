@@ -105,7 +105,9 @@ class GradientAverager:
 
     @staticmethod
     def _active():
-        return dist.is_initialized() and dist.get_world_size() > 1
+        # E3D_DDP_SINGLE_RANK=1: a one-rank process group still takes the whole data-parallel path (buckets, hooks, collectives
+        # over a group of one) -- how a one-GPU box exercises the RCCL calls (tools/lab/rccl_single_rank_step.py)
+        return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("E3D_DDP_SINGLE_RANK") == "1")
 
     def _buffer(self, i):
         bucket = self.buckets[i]

@@ -185,6 +185,26 @@ def test_joint_handover_helpers(pkg, hip):
     assert torch.equal(out[0, :5], traj[-1, 0, :5]) and float(out[0, 5:].abs().sum()) == 0.0
 
 
+def test_seeded_sampling_chain_is_the_same_replayed_or_launched(pkg, hip):
+    """a chain that DRAWS its categorical samples from torch's device generator (diverse=True, no injected
+    uniforms) must not depend on whether its steps are replayed from a graph -- a size threshold decides that.  The graph's
+    warm-up pass puts the generator back where it found it; equal seeds then give equal sequences on both paths (same kernels,
+    same philox offsets per step), or at the very least the same per-position class statistics."""
+    from e3diff_amd.sequence_model import sample as S
+    from e3diff_amd.sequence_model.utils import BlosumTransition, PredefinedNoiseScheduleDiscrete
+    cfg = dict(FULL_SEQ, num_hidden_layers=2)
+    B, L, T = 4, 64, 10
+    model, _ = build(pkg, cfg, L, seed=22)
+    pk = synthetic_pockets(B, L, seed=7, with_ligand_seq=True)
+    x_T = F.one_hot(torch.randint(0, 20, (B, L), generator=torch.Generator().manual_seed(5)), 20).float()
+    sched, trans = PredefinedNoiseScheduleDiscrete("cosine", T).to(DEV), BlosumTransition(x_classes=20)
+    outs = []
+    for g_ in (True, False):
+        torch.manual_seed(1234)
+        outs.append(S.denoise(pk, model, sched, trans, True, x_T=x_T, timesteps=T, use_graph=g_))
+    assert outs[0][2] == outs[1][2], "seeded chains differ between graph replay and eager launches"
+
+
 @pytest.mark.parametrize("diverse", [False, True])
 def test_denoise_graph_replay_is_bit_identical_to_eager_launches(pkg, hip, diverse):
     """sequence_model/sample.py::denoise with the reverse step replayed from a HIP graph (GraphedDenoiseStep: default for
