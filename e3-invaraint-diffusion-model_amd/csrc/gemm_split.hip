@@ -1044,7 +1044,7 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         g_general_form = e ? atoi(e) : 0;
     }
     int form = g_general_form;
-    if (form != 1 && form != 2 && form != 3) {
+    if (form != 1 && form != 2 && form != 3 && form != 4) {
         const int64_t g256 = (int64_t)((M + 255) / 256) * ((N + 127) / 128), g128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
         const int64_t cus = e3d_cu_count();
         if (NS == 3) form = g256 < 128 && !A_KMAJ && !B_KMAJ ? 2 : 1;       // 3-term kernels: as measured in round 1
@@ -1055,6 +1055,16 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         // against 32.5 (4-wave 128x128) / 36.9, N = 2304 70 against 81; M = 8192: form 1 by 4 %)
         else form = 25 * ((g128 + cus - 1) / cus) <= 38 * ((g256 + cus - 1) / cus) ? 3 : 1;
     }
+    // form 4 (round 4, selectable only: E3D_GEMM_FORM=4 / e3d_gemm_general_select(4)): 128x64 tiles on FOUR waves -- 48 KB of LDS,
+    // so up to three workgroups share a CU with barriers of their own.  Standalone (hot operands, tools/lab/gemm_forms_ab.py) a
+    // CU carrying 1 / 2 / 3 such workgroups takes ~20 / 28 / 41 us at K = 768 against ~24.5 us per round of 128x128 tiles (M =
+    // 2048 x N = 768: 20.1 vs 23.5 us, M = 8192 x N = 768: 42.6 vs 48.1) -- and inside the sequence training step (M = 8192,
+    // cold operands, neighbours on the queue) a shape rule built on those figures changed nothing: 19.9 vs 19.9 ms, three
+    // interleaved pairs (profiles/r04_gemm_form4_128x64_ab.log).  Not dispatched by shape.
+    if constexpr (NS == 2 && !A_KMAJ && !B_KMAJ) {
+        if (form == 4) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E, 1>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
+    }
+    if (form == 4) form = 3;
     if constexpr (NS <= 2 && !A_KMAJ) {
         // form 3: the 128x128 tile on EIGHT waves (2 x 4, each 64x32): two waves per SIMD cover each other's staging.
         // (The same form with k-tiles of 64 -- half the k-steps, 128 KB of LDS -- was built and measured: 27.3 against

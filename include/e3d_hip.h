@@ -154,8 +154,10 @@ int e3d_gemm_skinny_residual_layernorm_f32_split_ex(const float* A, int64_t lda,
  * accumulation order).  pref < 0 only queries.  Returns the previous value. */
 int e3d_gemm_kernel_select(int pref);
 /* The same for the general kernel (every launch the persistent / 256x256 forms do not take: medium and small M, the
- * training layouts): 0 = by shape (default), 1 = 256x128 tiles (8 waves), 2 = 128x128 (4 waves).  Identical results
- * in every form (up to the order of the split-K atomics of the weight-gradient layout).  form < 0 only queries. */
+ * training layouts): 0 = by shape (default), 1 = 256x128 tiles (8 waves), 2 = 128x128 (4 waves), 3 = 128x128 on 8 waves,
+ * 4 = 128x64 on 4 waves (48 KB of LDS: up to three workgroups per CU; forward / input-gradient layout of the 2-term
+ * arithmetics, other layouts fall back to 3).  Identical results in every form (up to the order of the split-K atomics of
+ * the weight-gradient layout).  form < 0 only queries. */
 int e3d_gemm_general_select(int form);
 
 /* Diagnostic (tests/test_kernels_gpu.py): the cooperative bf16x3 attention kernel keeps its running softmax maximum
