@@ -145,6 +145,12 @@ tf = [ln for ln in log_lines(f"{tag}_train_final.log", "training step")]
 if tf:
     row("training step without the profiler (`tools/bench_train.py <model> --steps 20`, two runs each)",
         "; ".join(re.sub(r" training step:.*graph=\w+: ", ": ", ln).split(" = ")[0] for ln in tf), f"`profiles/{tag}_train_final.log`")
+c3 = jload(f"{tag}_config3_full_chain.json")
+if c3:
+    row("BASELINE configs[2] end to end, once: the whole T = 1000 chain through `p_sample_loop` (product path: pocket encoder once per chain, bound-checked padding skip)",
+        f"{c3['chain_s']:.1f} s for {c3['trajectory_shape'][0]} steps × {c3['trajectory_shape'][1]} pockets = {c3['ms_per_step']:.1f} ms per step = {c3['pocket_steps_per_s']:.0f} pocket-steps/s; "
+        f"trajectory {c3['trajectory_GiB']:.2f} GiB on the device, copied out once in {c3['copy_out_s']:.2f} s; all finite: {c3['all_finite']}, inside [−π, π]: {c3['within_pi']}; peak memory {c3['peak_mem_GiB']:.1f} GiB",
+        f"`profiles/{tag}_config3_full_chain.json` (`python tools/lab/config3_full_chain.py`)")
 if rccl:
     g, e, s = rccl["rccl_one_rank_graph_segments"], rccl["rccl_one_rank_eager"], rccl["single_process_graph"]
     row("data-parallel step on RCCL, one-rank process group (the box has one GPU; `E3D_DDP_SINGLE_RANK=1`)",
