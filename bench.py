@@ -493,6 +493,12 @@ def main():
                 "launches_per_step": len(rowln), "algorithmic_flops_per_launch": rowln_flops,
                 "algorithmic_bytes_per_launch": rowln_bytes,
                 "hbm_algorithmic_GBps": rowln_bytes / (rowln_ms * 1e-3) / 1e9 if rowln else None,
+                # HBM-side bytes per launch from the PMC passes of tools/profile_round.sh (per K, M = 65536), averaged over the
+                # step's own mix of K; null when a launch has a shape the passes did not cover
+                "traffic": (lambda per: (sum(per) / len(per)) if per and all(v is not None for v in per) else None)(
+                    [tdict.get(f"gemm_rowln_M{int(m[0])}_K{int(m[2])}_hbm_bytes_per_launch") if os.path.exists(tj) else None
+                     for _, m in rowln]),
+                "traffic_source": traffic_source,
                 "replaces": "gemm_split256p_kernel<ACT_NONE> + residual_layernorm_kernel (E3D_GEMM_ROWLN=0 runs that pair)"},
             "gemm_shapes": shapes,
             "roofline_gemm": {"kernel": f"GEMM ({args.gemm_mode}), all launches of one step", "bound": "mfma",

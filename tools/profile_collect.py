@@ -58,6 +58,18 @@ traffic = {
         "command": "bash tools/profile_round.sh && python tools/profile_collect.py",
     },
 }
+# the row-complete GEMM + LayerNorm kernel (tools/lab/rowln_one.py: the first half of its launches are K = 768, the second K = 1024)
+if os.path.exists(f"{O}/pmc_rfetch/r_counter_collection.csv") and os.path.exists(f"{O}/pmc_rwrite/r_counter_collection.csv"):
+    rf, rw = counter_rows(f"{O}/pmc_rfetch/r_counter_collection.csv", ("gemm_rowln_kernel",)), counter_rows(f"{O}/pmc_rwrite/r_counter_collection.csv", ("gemm_rowln_kernel",))
+    if rf and rw and len(rf) == len(rw) and len(rf) % 2 == 0:
+        h = len(rf) // 2
+        for K, lo, hi in ((768, 0, h), (1024, h, 2 * h)):
+            f, w = mean(rf[lo:hi])[0], mean(rw[lo:hi])[0]
+            traffic[f"gemm_rowln_M65536_K{K}_hbm_bytes_per_launch"] = (2 * f + w) * 1024
+            traffic["_detail"].setdefault("rowln", {})[f"K{K}"] = {"FETCH_SIZE_KiB_raw_avg": f, "WRITE_SIZE_KiB_avg": w,
+                                                                   "algorithmic_bytes": 4 * (65536 * K + 2 * 65536 * 768 + 768 * K + 3 * 768)}
+        dump(rf, f"{tag}_gemm_rowln_M65536_pmc_fetch.csv")
+        dump(rw, f"{tag}_gemm_rowln_M65536_pmc_write.csv")
 json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 dump(af, f"{tag}_attn_coop_B256_L256_pmc_fetch.csv")
 dump(aw, f"{tag}_attn_coop_B256_L256_pmc_write.csv")

@@ -13,6 +13,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o a -- python3 $
 # the dominant GEMM kernel symbol over one whole bench step (every launch of it, as bench.py's `roofline` prices it)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_gfetch -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_gwrite -o g -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only > $O/pmc_gwrite.log 2>&1
+# the row-complete GEMM + LayerNorm kernel alone (6 launches at K = 768, then 6 at K = 1024; M = 65536)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rfetch -o r -- python3 $R/tools/lab/rowln_one.py > $O/pmc_rfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_rwrite -o r -- python3 $R/tools/lab/rowln_one.py > $O/pmc_rwrite.log 2>&1
 find $O -name "*.csv" | head -20
 # the rel-key attention kernel at L = 64 / 128 / 256 (rocprofv3 evidence instead of HIP events only)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_attn -o attn -- python3 $R/tools/bench_kernels.py attn_shapes > $O/attn_shapes.log 2>&1

@@ -93,7 +93,8 @@ if final:
     rl = final.get("roofline_gemm_layernorm")
     if rl:
         row("`roofline_gemm_layernorm` (`gemm_rowln_kernel`: dense + bias + residual + LayerNorm)",
-            f"{rl.get('launches_per_step', '?')} launches per step × {rl['avg_launch_ms'] * 1e3:.1f} µs = {rl['achieved']:.0f} TFLOP/s = {rl['frac']:.3f} of {rl['peak']:.0f}", src)
+            f"{rl.get('launches_per_step', '?')} launches per step × {rl['avg_launch_ms'] * 1e3:.1f} µs = {rl['achieved']:.0f} TFLOP/s = {rl['frac']:.3f} of {rl['peak']:.0f}"
+            + (f"; traffic {rl['traffic'] / 1e6:.0f} MB per launch vs {rl['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic" if rl.get("traffic") else ""), src)
     t = final.get("train")
     if t:
         def ms(k):
