@@ -448,6 +448,46 @@ def test_transposed_weight_registry_refreshes_all_stale_weights_together(pkg, hi
         assert torch.equal(AG._transposed_weight(w), w.detach().t())
 
 
+def test_purged_transposes_are_parked_while_another_captured_step_may_use_them(pkg, hip):
+    """a training step about to be captured drops the W^T entries of every OTHER model from the registry
+    (autograd.forget_transposes) -- but another model's captured step may still be alive, and its graph baked both the refresh
+    launches that write those buffers and the input-gradient GEMMs that read them.  The dropped entries are therefore parked
+    (their buffers stay allocated, at the same addresses, with the same contents) until release_retired_transposes()."""
+    from e3diff_amd import autograd as AG
+    mine = torch.nn.Parameter(torch.randn(256, 128, generator=g(40)).to(DEV))
+    other = torch.nn.Parameter(torch.randn(384, 128, generator=g(41)).to(DEV))
+    t_mine, t_other = AG._transposed_weight(mine), AG._transposed_weight(other)
+    ptr_other, parked_before = t_other.data_ptr(), len(AG._WT_RETIRED)
+    AG.forget_transposes({id(mine)})
+    assert (id(mine),) in AG._WT_REGISTRY and (id(other),) not in AG._WT_REGISTRY
+    assert len(AG._WT_RETIRED) == parked_before + 1 and AG._WT_RETIRED[-1].wt.data_ptr() == ptr_other
+    junk = [torch.empty_like(t_other) for _ in range(4)]                 # the allocator must not hand the parked buffer out
+    assert all(j.data_ptr() != ptr_other for j in junk)
+    assert torch.equal(AG._WT_RETIRED[-1].wt, other.detach().t())
+    assert AG._transposed_weight(mine) is t_mine                          # the keeper is untouched
+    AG.release_retired_transposes()
+    assert AG._WT_RETIRED == []
+
+
+def test_f16x3_weight_cache_miss_inside_a_capture_is_loud(pkg, hip):
+    """building the pre-scaled f16x3 copy of a weight reads max |w| back to the host, which a stream capture
+    cannot do; it used to fall back silently to the RAW weight (a graph captured that way would run f16x3 on un-pre-scaled
+    weights at every replay).  Now it raises; warmed up, the same call inside a capture hits the cache."""
+    from e3diff_amd import ops
+    w = torch.randn(64, 64, generator=g(42)).to(DEV) * 1e-4
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="pre-scaled copy"):
+        with torch.cuda.graph(graph):
+            ops.f16_weight(w)
+    torch.cuda.synchronize()
+    scaled, inv = ops.f16_weight(w)                                       # eager: fills the cache
+    assert inv != 1.0 and torch.equal(scaled * inv, w)
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        again, inv2 = ops.f16_weight(w)
+    assert again is scaled and inv2 == inv
+
+
 def test_deferred_weight_gradient_queue_flushes_early_past_its_memory_budget(pkg, hip, Fm, monkeypatch):
     """the queue keeps every (dz, x) pair alive until the end of backward.  Past E3D_DEFER_WGRAD_MAX_GB it
     computes what is queued and goes on -- same gradients, every parameter reported to a listener exactly once and only
