@@ -224,18 +224,37 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     constexpr int NSET = DEEP ? 2 : 1;
     f32x4 sk[NSET][NI], sv[NSET][NI];
     float smask[NSET];
+    // Staging loads through BUFFER descriptors (round 4): a tile's base (rows r0 ..) and its byte count are wave-uniform and
+    // live in the descriptor's SGPRs, the per-item offset inside a tile never changes -- so a tile's four loads need no
+    // vector address arithmetic at all (the flat form spent ~20 VALU instructions per tile on clamps and 64-bit adds), and
+    // rows past the last key come back as zeros from the hardware's range check (the flat form re-read row Lk - 1; either
+    // way those keys carry a bias of -inf).  The range check covers the vector offset only, hence base = tile, not item.
+    int voff_k[NI], voff_v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = tid + NT * i;
+        voff_k[i] = ((f >> 4) * (int)k_rs + 4 * (f & 15)) * 4;
+        voff_v[i] = ((f >> 4) * (int)v_rs + 4 * (f & 15)) * 4;
+    }
+    const int voff_m = (tid & 31) * 4;
+    auto tile_rsrc = [&](const float* base, int64_t rs, int r0, int tail_floats) {
+        const int rows = Lk - r0;                                                    // >= 1 (callers clamp the tile index)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)r0 * rs), 0,
+                                                 (int)(((int64_t)(rows - 1) * rs + tail_floats) * 4), 0x00020000);
+    };
     auto stage_load = [&](auto set_tag, int r0) {
         constexpr int SET = decltype(set_tag)::value;
+        const auto rk = tile_rsrc(kb_, k_rs, r0, D), rv = tile_rsrc(vb_, v_rs, r0, D);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int f = tid + NT * i;
-            const int key = min(r0 + (f >> 4), Lk - 1);
-            sk[SET][i] = *reinterpret_cast<const f32x4*>(kb_ + (unsigned)(key * (int)k_rs + 4 * (f & 15)));
-            sv[SET][i] = *reinterpret_cast<const f32x4*>(vb_ + (unsigned)(key * (int)v_rs + 4 * (f & 15)));
+            sk[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voff_k[i], 0, 0));
+            sv[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voff_v[i], 0, 0));
         }
         // key-mask value of key r0 + (tid & 31): loaded by every thread (no branch around a load: hipcc then
-        // counts vmcnt exactly), used by the first 32
-        smask[SET] = mb ? mb[min(r0 + (tid & 31), Lk - 1)] : 1.0f;
+        // counts vmcnt exactly), used by the first 32; without a mask the K rows stand in (value unused)
+        const auto rm = tile_rsrc(mb ? mb : kb_, 1, r0, 1);
+        const float mval = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, voff_m, 0, 0));
+        smask[SET] = mb ? mval : 1.0f;
     };
     auto stage_store = [&](auto set_tag, int r0, unsigned char* buf) {
         constexpr int SET = decltype(set_tag)::value;
@@ -260,12 +279,18 @@ __global__ __launch_bounds__(W * 64, 2) void attn_coop_kernel(
     // rel-key: E fragments of block j (distance-table rows P + 32 (j - J0) .. + 31) from the fragment-order planes
     bf16x8 ef[4][2];
     const int J0 = (Lk + 31) >> 5, qt = q0 >> 5;
+    // (buffer loads as well: block j is a wave-uniform scalar offset, the lane's offset and the k-block / plane offsets are
+    //  constants: no vector address arithmetic per tile)
+    const auto e_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8*>(e_frag ? e_frag : reinterpret_cast<const bf16x8*>(k)), 0,
+                                                          2 * ((Lk + 31) >> 5) * 512 * 16, 0x00020000);
+    const int voff_e = lane * 16;
     auto e_load = [&](int j) {
-        const bf16x8* pj = e_frag + (size_t)j * 512 + lane;
+        const int so = __builtin_amdgcn_readfirstlane(j * 8192);   // (j comes from the wave index: uniform, but hipcc cannot prove it
+                                                                   //  and would wrap every load in a waterfall loop)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            ef[kb][0] = pj[kb * 64];
-            ef[kb][1] = pj[256 + kb * 64];
+            ef[kb][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(e_rsrc, voff_e + kb * 1024, so, 0));
+            ef[kb][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(e_rsrc, voff_e + kb * 1024, so + 4096, 0));
         }
     };
     auto dot_q_acc = [&](const bf16x8 (&x)[4][2], f32x16 acc) {

@@ -404,7 +404,10 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     // the cooperative kernel reads the distance table as fragment-order bf16 planes from a CALLER-provided scratch
     // (e3d_attn_scratch_bytes); without one the per-wave kernel below serves the call -- the library never allocates.
     // With dropout (training) the cooperative kernel exists in bf16x3.
-    if ((terms == 3 || (f16 && !dropping)) && coop && v_rs % 4 == 0 && v_bs % 4 == 0 && ((Lq + 31) / 32) % 4 == 0 &&
+    // (its staging goes through buffer descriptors of one key tile's rows: 32-bit byte offsets and record counts, i.e. an
+    //  item's K / V rows must span less than 2 GiB -- Lk x row stride x 4 bytes; the per-wave kernel serves anything wider)
+    const bool span_ok = (int64_t)Lk * (k_rs > v_rs ? k_rs : v_rs) * 4 < ((int64_t)1 << 31) && k_rs > 0 && v_rs > 0;
+    if ((terms == 3 || (f16 && !dropping)) && coop && span_ok && v_rs % 4 == 0 && v_bs % 4 == 0 && ((Lq + 31) / 32) % 4 == 0 &&
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
                                     Lq, Lk, g_skip_padded, bnd, e_scratch, e_scratch_ready, f16, d, dropping, s);
