@@ -179,40 +179,49 @@ struct StagerT {
     static constexpr int NV = ROWS * 8 / NT;
     static constexpr int PITCH = ROWS * 2, Q = ROWS / 4, KSTEP = NT / Q;   // KSTEP: k-rows one pass of the workgroup covers
     static_assert(KSTEP * NV == 32, "a k-tile is 32 k-rows");
-    const float* src;       // operand base + this thread's 4 rows (clamped at the edge: those outputs are discarded)
+    // Loads go through a BUFFER descriptor of the k-tile's rows (round 4): base = operand + k0 * ld and the byte count up to
+    // the end of reduction row K - 1 are wave-uniform (SGPRs), a thread's offsets inside a k-tile never change -- so a load
+    // needs no vector address arithmetic, and reduction rows >= K come back as ZEROS from the hardware's range check: the
+    // per-k-step clamp (v_min + 64-bit multiply-add per item) and the tail masking (4 v_cndmask per item) of the flat form,
+    // 48 of 254 instructions per k-step and wave in the ragged weight-gradient kernel, are gone.
+    const float* ubase;     // operand base: wave-uniform (kernel argument / problem table)
     int64_t ld;
-    int kk0, n4;
+    int kk0, n4, lim;
+    int voff[NV];           // byte offset of item i inside a k-tile: ((kk0 + KSTEP i) ld + first row) 4
 
     __device__ __forceinline__ void init(const float* base, int64_t ld_, int row0, int row_limit, int tid) {
         ld = ld_;
+        ubase = base;
+        lim = row_limit;
         n4 = tid % Q;
         kk0 = tid / Q;
         const int gr = min(row0 + 4 * n4, row_limit - 4);     // row_limit % 4 == 0 (checked by the launcher)
-        src = base + gr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) voff[i] = (int)(((int64_t)kk(i) * ld + gr) * 4);
     }
     __device__ __forceinline__ int kk(int i) const { return kk0 + KSTEP * i; }
     __device__ __forceinline__ int off(int i) const {
         const int k = kk(i);
         return k * PITCH + (((n4 >> 2) ^ (2 * (k & 3))) << 5) + (n4 & 3) * 8;
     }
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(int k0, int K) const {
+        // rows k0 .. K - 1 of the operand (callers keep k0 < K); the range check covers the vector offset only
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase + (int64_t)k0 * ld), 0,
+                                                 (int)(((int64_t)(K - 1 - k0) * ld + lim) * 4), 0x00020000);
+    }
     __device__ __forceinline__ void load_item(int i, f32x4& v, int k0, int K) const {
-        const int k = min(k0 + kk(i), K - 1);                 // the K tail is zeroed at store time
-        v = *reinterpret_cast<const f32x4*>(src + (int64_t)k * ld);
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(k0, K), voff[i], 0, 0));
     }
     __device__ __forceinline__ void load(f32x4 (&v)[NV], int k0, int K) const {
+        const auto r = tile_rsrc(k0, K);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) load_item(i, v[i], k0, K);
+        for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff[i], 0, 0));
     }
-    __device__ __forceinline__ f32x4 masked(int i, const f32x4& v, int k0, int K) const {
-        const bool in = k0 + kk(i) < K;
-        f32x4 r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = in ? v[j] : 0.f;
-        return r;
-    }
+    // (reduction rows past K inside a k-tile were loaded as zeros: nothing to mask per row.  What remains is the WHOLE tile past
+    //  the end: the pipeline's last steps re-load the last k-tile under a logical k0 >= K -- a wave-uniform test)
+    __device__ __forceinline__ f32x4 masked(int, const f32x4& v, int k0, int K) const { return k0 < K ? v : f32x4{0.f, 0.f, 0.f, 0.f}; }
     template <int NS, typename E>
-    __device__ __forceinline__ void store_item(int i, const f32x4& vin, unsigned char* img, int part_bytes, int k0, int K) const {
-        const f32x4 v = masked(i, vin, k0, K);
+    __device__ __forceinline__ void store_item(int i, const f32x4& v, unsigned char* img, int part_bytes, int, int) const {
         typename Vec<E>::x4 p[NS];
         split4<NS, E>(v, p);
         const int o = off(i);
