@@ -174,6 +174,9 @@ struct Stager {
 // the order 4 half + (j & 3) + 8 (j >> 2) inside a 16-block: the same for both operands, so the contraction is intact).
 // 32-byte units (16 rows of one k) are XOR-ed by 2 (k & 3): the 4 k-rows x 2 units a 32-lane half of a transposing read
 // touches then fall into 8 distinct 8-bank windows, and a wave's 8-byte writes still cover whole k-rows.
+// (host) the transposing stager's buffer descriptors count bytes in 32 bits: reduction length x row stride x 4 < 2 GiB
+static inline bool e3d_tr_span_ok(int64_t k_len, int64_t ld) { return k_len > 0 && ld > 0 && k_len * ld * 4 < ((int64_t)1 << 31); }
+
 template <int ROWS, int NT>
 struct StagerT {
     static constexpr int NV = ROWS * 8 / NT;
@@ -1086,7 +1089,10 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
     if (form == 2) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     if constexpr (A_KMAJ && B_KMAJ) {   // weight-gradient layout: the transposing staging when both operands come in whole quads
         static const bool tr_on = !getenv("E3D_WGRAD_TR") || atoi(getenv("E3D_WGRAD_TR")) != 0;
-        if (tr_on && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0)
+        // (the transposing stager addresses a k-tile's rows through a buffer descriptor: 32-bit byte counts, so the reduction
+        //  length times the row stride must stay under 2 GiB -- e3d_tr_span_ok; wider problems keep the dword staging)
+        if (tr_on && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 &&
+            e3d_tr_span_ok(K, lda) && e3d_tr_span_ok(K, ldb))
             return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E, 2, true>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     }
     return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 4, 2, E>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
@@ -1239,7 +1245,7 @@ extern "C" int e3d_gemm_wgrad_grouped_f32_split(const float* const* dz, const fl
     g.accumulate = accumulate_bits;
     // transposing staging (float4 loads along the contiguous index, ds_read_b64_tr_b16 fragments): whole quads only
     static const bool tr_on = !getenv("E3D_WGRAD_TR") || atoi(getenv("E3D_WGRAD_TR")) != 0;
-    bool tr = tr_on && N % 4 == 0 && K % 4 == 0 && ldz % 4 == 0 && ldx % 4 == 0;
+    bool tr = tr_on && N % 4 == 0 && K % 4 == 0 && ldz % 4 == 0 && ldx % 4 == 0 && e3d_tr_span_ok(M, ldz) && e3d_tr_span_ok(M, ldx);
     for (int p = 0; p < count && tr; ++p) tr = ((uintptr_t)dz[p] % 16) == 0 && ((uintptr_t)x[p] % 16) == 0;
     const int tiles_m = (N + 255) / 256, tiles_n = (K + 127) / 128;
     E3D_REQUIRE((int64_t)tiles_m * tiles_n * count < (1ll << 30), "gemm_wgrad_grouped: too many tiles");
@@ -1289,7 +1295,7 @@ extern "C" int e3d_gemm_wgrad_ragged_f32_split(const float* const* dz, const flo
         if (p < count) {
             tiles += (int64_t)((N[q] + 255) / 256) * ((K[q] + 127) / 128);
             tr = tr && N[q] % 4 == 0 && K[q] % 4 == 0 && ldz[q] % 4 == 0 && ldx[q] % 4 == 0 && ((uintptr_t)dz[q] % 16) == 0 &&
-                 ((uintptr_t)x[q] % 16) == 0;
+                 ((uintptr_t)x[q] % 16) == 0 && e3d_tr_span_ok(M, ldz[q]) && e3d_tr_span_ok(M, ldx[q]);
         }
     }
     E3D_REQUIRE(tiles < (1ll << 30), "gemm_wgrad_ragged: too many tiles");
