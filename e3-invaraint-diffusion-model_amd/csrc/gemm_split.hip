@@ -175,7 +175,10 @@ struct Stager {
 // 32-byte units (16 rows of one k) are XOR-ed by 2 (k & 3): the 4 k-rows x 2 units a 32-lane half of a transposing read
 // touches then fall into 8 distinct 8-bank windows, and a wave's 8-byte writes still cover whole k-rows.
 // (host) the transposing stager's buffer descriptors count bytes in 32 bits: reduction length x row stride x 4 < 2 GiB
-static inline bool e3d_tr_span_ok(int64_t k_len, int64_t ld) { return k_len > 0 && ld > 0 && k_len * ld * 4 < ((int64_t)1 << 31); }
+// (and a k-tile's 32 rows must fit a 32-bit vector offset whatever the reduction length)
+static inline bool e3d_tr_span_ok(int64_t k_len, int64_t ld) {
+    return k_len > 0 && ld > 0 && ld < ((int64_t)1 << 24) && k_len * ld * 4 < ((int64_t)1 << 31);
+}
 
 template <int ROWS, int NT>
 struct StagerT {
