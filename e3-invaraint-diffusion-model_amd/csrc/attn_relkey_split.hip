@@ -406,7 +406,8 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     // With dropout (training) the cooperative kernel exists in bf16x3.
     // (its staging goes through buffer descriptors of one key tile's rows: 32-bit byte offsets and record counts, i.e. an
     //  item's K / V rows must span less than 2 GiB -- Lk x row stride x 4 bytes; the per-wave kernel serves anything wider)
-    const bool span_ok = (int64_t)Lk * (k_rs > v_rs ? k_rs : v_rs) * 4 < ((int64_t)1 << 31) && k_rs > 0 && v_rs > 0;
+    const bool span_ok = (int64_t)Lk * (k_rs > v_rs ? k_rs : v_rs) * 4 < ((int64_t)1 << 31) && k_rs > 0 && v_rs > 0 &&
+                         k_rs < ((int64_t)1 << 24) && v_rs < ((int64_t)1 << 24);     // (a tile's 32 rows in a 32-bit offset)
     if ((terms == 3 || (f16 && !dropping)) && coop && span_ok && v_rs % 4 == 0 && v_bs % 4 == 0 && ((Lq + 31) / 32) % 4 == 0 &&
         (!dist_emb || e_scratch))
         return e3d_attn_coop_launch(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, dist_emb, P, key_mask, out, lse, B, nh,
