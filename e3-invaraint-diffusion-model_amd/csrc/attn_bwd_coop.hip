@@ -39,10 +39,21 @@ constexpr int PLANE_B = MAX_TILES * 32 * ROW_B;    // one plane (hi or lo) of on
 constexpr int IMG_B = 2 * PLANE_B;                 // hi + lo
 constexpr int RA_LD = 65, RB_LD = 34, X_LD = 33;
 constexpr int WAVE_F = 64 * RB_LD + 32 * X_LD;     // per-wave scratch floats: phase B ring + X (phase A ring 32 x 65 fits)
-constexpr int ROWS_F = 3 * MAX_TILES * 32;         // lse2, delta, key bias
+constexpr int ROWS_F = 3 * MAX_TILES * 32 + 32;    // lse2, delta, key bias (+ 32 words: query-tile liveness flags, round 4)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float S_SCALE = 0.125f * LOG2E;
 constexpr size_t LDS_BYTES = 2 * IMG_B + (ROWS_F + 4 * WAVE_F) * sizeof(float);
+
+#ifdef BWD_STAMPS   // lab builds only (tools/lab/attn_bwd_stamps.py): s_memrealtime (100 MHz) stamps per workgroup and wave
+__device__ long long bwd_stamps[2][512][4][8];
+#define BSTAMP(slot)                                                                                           \
+    do {                                                                                                       \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 512)                                                       \
+            bwd_stamps[blockIdx.y][blockIdx.x][threadIdx.x >> 6][(slot)] = __builtin_amdgcn_s_memrealtime();   \
+    } while (0)
+#else
+#define BSTAMP(slot) do {} while (0)
+#endif
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -235,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     float* kbias = delta + MAX_TILES * 32;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
-    float* scratch = kbias + MAX_TILES * 32 + wid * WAVE_F;
+    int* q_live = reinterpret_cast<int*>(kbias + MAX_TILES * 32);   // [q tile] != 0: some dO row of the tile is not all zeros
+    float* scratch = kbias + MAX_TILES * 32 + 32 + wid * WAVE_F;
     const int bh = xcd_remap(blockIdx.x, gridDim.x), h = bh % nh, b = bh / nh;
     const int PHASE = blockIdx.y;
     const int q_tiles = (Lq + 31) >> 5, k_tiles = (Lk + 31) >> 5;
@@ -248,28 +260,82 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     const float* dob = dout + (int64_t)b * Lq * HD + h * D;
     const float* ob = outp + (int64_t)b * Lq * HD + h * D;
 
+    BSTAMP(0);
     // ---- prologue: the phase's two images, per-row softmax constants ------------------------------------------------
-    if (PHASE == 0) {
-        stage_image(img0, qb, q_rs, Lq, q_tiles, tid);
-        stage_image(img1, dob, HD, Lq, q_tiles, tid);
-    } else {
-        stage_image(img0, kb_, k_rs, Lk, k_tiles, tid);
-        stage_image(img1, vb, v_rs, Lk, k_tiles, tid);
-    }
-    for (int f = tid; f < q_tiles * 32 * 16; f += 256) {   // delta[q] = sum_d dO[q][d] O[q][d]: 16 consecutive threads per row
-        const int row = f >> 4, c4 = f & 15, rc = min(row, Lq - 1);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(dob + (int64_t)rc * HD + 4 * c4);
-        const f32x4 o = *reinterpret_cast<const f32x4*>(ob + (int64_t)rc * HD + 4 * c4);
-        float part = (a[0] * o[0] + a[1] * o[1]) + (a[2] * o[2] + a[3] * o[3]);
+    // Every global read of the prologue is ISSUED before the first one is used (round 4): with one workgroup per CU and one
+    // wave per SIMD nothing else covers a load's latency, and the rolled staging loops this replaces paid it 24 times in a
+    // row (8 trips x {image 0, image 1, delta}) -- more than the tile loops of a BioLiP-shaped ligand take.  Thread tid owns
+    // the float4 items tid + 256 i (row = item / 16): the same mapping for the images and for delta, so phase 0 reads dO once.
+    constexpr int NI = MAX_TILES * 2;              // float4 items per thread and array
+    const float* src0 = PHASE == 0 ? qb : kb_;
+    const float* src1 = PHASE == 0 ? dob : vb;
+    const int64_t rs0 = PHASE == 0 ? q_rs : k_rs, rs1 = PHASE == 0 ? (int64_t)HD : v_rs;
+    const int rows01 = PHASE == 0 ? Lq : Lk, tiles01 = PHASE == 0 ? q_tiles : k_tiles;
+    f32x4 x0[NI], x1[NI], xd[NI], xo[NI];
 #pragma unroll
-        for (int s = 1; s < 16; s <<= 1) part += __shfl_xor(part, s, 64);
-        if (c4 == 0) delta[row] = part;
+    for (int i = 0; i < NI; ++i) {
+        const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+        if (i < 2 * tiles01) {                     // (workgroup-uniform)
+            const int rc = min(row, rows01 - 1);
+            x0[i] = *reinterpret_cast<const f32x4*>(src0 + (int64_t)rc * rs0 + 4 * c4);
+            x1[i] = *reinterpret_cast<const f32x4*>(src1 + (int64_t)rc * rs1 + 4 * c4);
+        }
+        if (i < 2 * q_tiles) {
+            const int rc = min(row, Lq - 1);
+            xo[i] = *reinterpret_cast<const f32x4*>(ob + (int64_t)rc * HD + 4 * c4);
+            if (PHASE == 1) xd[i] = *reinterpret_cast<const f32x4*>(dob + (int64_t)rc * HD + 4 * c4);
+        }
     }
-    for (int i = tid; i < MAX_TILES * 32; i += 256) {
-        lse2[i] = i < Lq ? lse[((int64_t)b * nh + h) * Lq + i] * LOG2E : 0.f;
-        kbias[i] = (i < Lk && key_mask) ? (1.0f - key_mask[(int64_t)b * Lk + i]) * (-10000.0f * LOG2E) : 0.f;
+    float lse_in = 0.f, mask_in = 1.f;
+    if (tid < MAX_TILES * 32) {
+        if (tid < Lq) lse_in = lse[((int64_t)b * nh + h) * Lq + tid];
+        if (tid < Lk && key_mask) mask_in = key_mask[(int64_t)b * Lk + tid];
+    }
+    // Dead query tiles (round 4).  A query row whose dO is ALL ZEROS contributes exact zeros to everything this kernel sums
+    // (dP = dO V^T = 0, delta = 0, so dS = P (dP - delta) = 0; dV += dO^T P gets 0) and its own dQ row is 0: in training that is
+    // every padded position -- the loss never sees them and, masked as keys, nothing valid depends on them -- i.e. 3 of the 4
+    // query tiles of a BioLiP-shaped ligand (5-30 residues in a 128-row frame).  Found from the data itself while delta is
+    // formed (no mask argument, nothing to prove: a tile with one nonzero dO element is simply alive); skipping is bit-exact.
+    if (tid < 32) q_live[tid] = 0;
+    __syncthreads();
+#ifdef BWD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    BSTAMP(1);
+    auto to_image = [&](unsigned char* img, const f32x4& v, int row, int c4) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 p = (__bf16)v[j];
+            hi[j] = p;
+            lo[j] = (__bf16)(v[j] - (float)p);
+        }
+        const int o = img_off(row, c4 >> 1) + 8 * (c4 & 1);
+        *reinterpret_cast<bf16x4*>(img + o) = hi;
+        *reinterpret_cast<bf16x4*>(img + PLANE_B + o) = lo;
+    };
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = tid + 256 * i, row = f >> 4, c4 = f & 15;
+        if (i < 2 * tiles01) {
+            to_image(img0, x0[i], row, c4);
+            to_image(img1, x1[i], row, c4);
+        }
+        if (i < 2 * q_tiles) {                     // delta[q] = sum_d dO[q][d] O[q][d]: 16 consecutive threads per row
+            const f32x4 a = PHASE == 0 ? x1[i] : xd[i], o = xo[i];
+            if (row < Lq && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f)) q_live[row >> 5] = 1;
+            float part = (a[0] * o[0] + a[1] * o[1]) + (a[2] * o[2] + a[3] * o[3]);
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) part += __shfl_xor(part, sh, 64);
+            if (c4 == 0) delta[row] = part;
+        }
+    }
+    if (tid < MAX_TILES * 32) {
+        lse2[tid] = lse_in * LOG2E;
+        kbias[tid] = (tid < Lk && key_mask) ? (1.0f - mask_in) * (-10000.0f * LOG2E) : 0.f;
     }
     __syncthreads();
+    BSTAMP(2);
 
     // ================================================================================================ phase A: dK, dV
     if (PHASE == 0 && wid < k_tiles) {
@@ -281,7 +347,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
         const float bias_k = kbias[min(key, MAX_TILES * 32 - 1)];
         float* ring = scratch;                     // T[q][window x]: 32 x RA_LD
         f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+        BSTAMP(3);
         for (int qt = 0; qt < q_tiles; ++qt) {
+            if (!q_live[qt]) continue;             // (workgroup-uniform) every dO row of this query tile is zero: exact zeros
             Frag qa[4], da[4];
             row_frags(qa, img0, qt, lane);
             row_frags(da, img1, qt, lane);
@@ -313,6 +381,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 __builtin_amdgcn_wave_barrier();   // the next step's writes come after these reads
             }
             f32x16 ds;
+            bool any_p = false;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {          // rows 8 g + 4 half + j: lse2 / delta as 16-byte LDS reads
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + 32 * qt + 8 * g + 4 * half);
@@ -332,8 +401,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                     }
                     s[r] = p * mult;
                     ds[r] = p * (dp[r] * mult - d4[j]) * 0.125f;
+                    any_p = any_p || p != 0.f;
                 }
             }
+            // every probability of the pair is exactly 0.0f (an all-padding key tile whose exp underflowed, as the reference's
+            // additive -10000 makes it whenever the scores are of ordinary size): P = dS = 0, nothing to add (wave-uniform)
+            if (__builtin_amdgcn_ballot_w64(any_p) == 0ull) continue;
             // dV^T += dO^T P,  dK^T += Q^T dS: B = the accumulator tiles as they stand (k = query rows rho(8 st + j, half))
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -347,11 +420,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 dk1 = mfma3(tr_frag(img0, qt, st, 1, lane), sb, dk1);
             }
         }
+        BSTAMP(4);
         if (key_ok) {
             store_rows_T(dv0, dv1, dv + b * dv_bs + (int64_t)key * dv_rs + h * D, half);
             store_rows_T(dk0, dk1, dk + b * dk_bs + (int64_t)key * dk_rs + h * D, half);
         }
     }
+
+#ifdef BWD_STAMPS
+    if (PHASE == 0) { BSTAMP(5); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BSTAMP(6); }
+#endif
 
     // ================================================================================================ phase B: dQ, dE
     if (PHASE == 1 && wid < q_tiles) {
@@ -377,6 +455,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 }
         }
         float* part_base = RELKEY ? dE_part + ((int64_t)bh * q_tiles + qt) * (k_tiles + 1) * 32 * D : nullptr;
+        BSTAMP(3);
+        if (!q_live[qt]) {                         // (wave-uniform) dO of this wave's query tile is all zeros: dQ = 0, dE blocks = 0
+            if (RELKEY) {
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                for (int i = lane; i < (k_tiles + 1) * 32 * D / 4; i += 64) reinterpret_cast<f32x4*>(part_base)[i] = z4;
+            }
+            if (q_ok) store_rows_T(dq0, dq1, dq + b * dq_bs + (int64_t)qrow * dq_rs + h * D, half);
+#ifdef BWD_STAMPS
+            BSTAMP(4); BSTAMP(5); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BSTAMP(6);
+#endif
+            return;
+        }
         auto e_rows = [&](Frag (&ef)[4], int j) {
             const bf16x8* pj = e_row + (size_t)min(max(j, 0), 2 * J0 - 1) * 512 + lane;
 #pragma unroll
@@ -413,6 +503,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 rot ^= 32;
             }
             f32x16 ds;
+            bool any_p = false;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(kbias + r0 + 8 * g + 4 * half);
@@ -424,19 +515,36 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                     const bool ok = q_ok && (r0 + 8 * g + 4 * half + j) < Lk;
                     const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], S_SCALE, b4[j]) - lse_q) : 0.f;
                     ds[r] = p * (dp[r] * m4[j] - delta_q) * 0.125f;
+                    any_p = any_p || p != 0.f;
                 }
             }
+            // all 1024 probabilities of the pair exactly 0.0f (an all-padding key tile): dS = 0 -- no dQ term, no dE term; only
+            // the block bookkeeping of the distance-table gradient moves on (wave-uniform)
+            const bool dead_pair = __builtin_amdgcn_ballot_w64(any_p) == 0ull;
             // dQ^T += K^T dS^T
+            if (!dead_pair) {
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                float sv[8];
+                for (int st = 0; st < 2; ++st) {
+                    float sv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sv[j] = ds[8 * st + j];
-                const Frag sb = split8(sv);
-                dq0 = mfma3(tr_frag(img0, kt, st, 0, lane), sb, dq0);
-                dq1 = mfma3(tr_frag(img0, kt, st, 1, lane), sb, dq1);
+                    for (int j = 0; j < 8; ++j) sv[j] = ds[8 * st + j];
+                    const Frag sb = split8(sv);
+                    dq0 = mfma3(tr_frag(img0, kt, st, 0, lane), sb, dq0);
+                    dq1 = mfma3(tr_frag(img0, kt, st, 1, lane), sb, dq1);
+                }
             }
-            if (RELKEY) {
+            if (RELKEY && dead_pair) {
+                // the upper block is complete (nothing was added to either block by this tile)
+                float* blk = part_base + (int64_t)kt * 32 * D;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    blk[mfma32_row(r, half) * D + l31] = ehi0[r];
+                    blk[mfma32_row(r, half) * D + 32 + l31] = ehi1[r];
+                }
+                ehi0 = elo0; ehi1 = elo1;
+                elo0 = zero16(); elo1 = zero16();
+            }
+            if (RELKEY && !dead_pair) {
                 wave_lds_sync();   // the previous tile's readers of X are done
 #pragma unroll
                 for (int r = 0; r < 16; ++r) X[mfma32_row(r, half) * X_LD + l31] = ds[r];
@@ -497,6 +605,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 elo0 = zero16(); elo1 = zero16();
             }
         }
+        BSTAMP(4);
         if (RELKEY) {
             float* blk = part_base + (int64_t)k_tiles * 32 * D;
 #pragma unroll
@@ -505,9 +614,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
                 blk[mfma32_row(r, half) * D + 32 + l31] = ehi1[r];
             }
         }
+        BSTAMP(5);
         if (q_ok) store_rows_T(dq0, dq1, dq + b * dq_bs + (int64_t)qrow * dq_rs + h * D, half);
+#ifdef BWD_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BSTAMP(6);
+#endif
     }
 }
+
+#ifdef BWD_STAMPS
+extern "C" int e3d_debug_bwd_stamps(long long* t) {
+    return (int)hipMemcpyFromSymbol(t, HIP_SYMBOL(bwd_stamps), sizeof(long long) * 2 * 512 * 4 * 8);
+}
+#endif
 
 constexpr int DE_CHUNKS = 12;   // (b, head) chunks of the dE reduction's first stage
 
