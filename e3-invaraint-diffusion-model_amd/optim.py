@@ -75,6 +75,17 @@ class ClipAdamW(torch.optim.AdamW):
         tab["gptr_host"] = None      # the graph re-copies ITS gradient pointers: an eager step must upload its own again
         self._opt_called = True      # what LR schedulers look at to order scheduler.step() after optimizer.step()
 
+    def new_capture_staging(self):
+        """Call before capturing ANOTHER graph of the step: a captured ``step()`` uploads the addresses of its gradient
+        tensors from a pinned staging buffer, and every replay reads that buffer again -- so each graph needs its own (the
+        earlier ones stay alive here; a few KB each)."""
+        tab = self._e3d_tab
+        if tab is None:
+            return
+        tab.setdefault("gptr_pin_kept", []).append(tab["gptr_pin"])
+        tab["gptr_pin"] = torch.zeros_like(tab["gptr_pin"]).pin_memory()
+        tab["gptr_host"] = None
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._e3d_tab = None

@@ -71,6 +71,27 @@ def mean_over_ranks(value):
     return float(t.item()) / dist.get_world_size()
 
 
+_HOST_GROUP = None
+
+
+def max_over_ranks_host(values):
+    """Element-wise maximum of a few host integers over the ranks, on the host (a gloo group beside the RCCL one, made on
+    first use): nothing is enqueued on the GPU and nothing of the GPU is waited for, so the step before keeps running."""
+    values = [int(v) for v in values]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return tuple(values)
+    global _HOST_GROUP
+    if dist.get_backend() == "gloo":
+        group = None
+    else:
+        if _HOST_GROUP is None:
+            _HOST_GROUP = dist.new_group(backend="gloo")
+        group = _HOST_GROUP
+    t = torch.tensor(values, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return tuple(int(v) for v in t.tolist())
+
+
 class GradientAverager:
     """Bucketed all-reduce(sum)/world of parameter gradients, overlapped with the backward pass
     (``prepare`` before ``backward``, ``average`` after it).

@@ -74,8 +74,13 @@ class GraphedStep:
     lists); the learning rate and the AdamW step counts live in device memory (``ClipAdamW.use_device_scalars``); dropout
     decisions take a device-side epoch word on top of their baked seeds (``ops.dropout_epoch``), advanced inside the graph;
     derived-weight caches (W^T, distance-table planes) are refreshed by launches inside the captured backward / forward.
-    Batches with another signature (a ragged last batch) run eagerly.  Single process; the data-parallel step is
-    ``GraphedDDPStep`` (two segments around the collectives)."""
+    One graph per batch signature, up to ``MAX_GRAPHS`` of them (frames trimmed to the batch's longest ligand / pocket come
+    in a handful of shapes: ``trim_batch``); a signature seen fewer than ``warmup`` times, or beyond that number, runs
+    eagerly (a ragged last batch).  Every graph has its own memory pool, its own gradient tensors and its own staging
+    buffer for their addresses (``ClipAdamW.new_capture_staging``); parameters, moments, learning rate and step counts are
+    shared.  Single process; the data-parallel step is ``GraphedDDPStep`` (two segments around the collectives)."""
+
+    MAX_GRAPHS = 8
 
     def __init__(self, model, optim, params, gradient_clip, warmup=2):
         from .optim import ClipAdamW
@@ -83,7 +88,8 @@ class GraphedStep:
             raise TypeError("GraphedStep needs optim.ClipAdamW (device-side learning rate and step counts)")
         self.model, self.optim, self.params, self.clip = model, optim, params, gradient_clip
         self.warmup, self.seen = warmup, {}
-        self.graph = self.key = self.static = self.loss = None
+        self.graphs = {}                             # signature -> the captured step (graph, static batch, loss tensor)
+        self.graph = self.key = self.static = self.loss = None   # ... and the one used last
         self.failed = None
         optim.use_device_scalars(True)
         self.epoch = ops.dropout_epoch(params[0].device)
@@ -117,6 +123,7 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         self.optim.zero_grad(set_to_none=True)       # the gradients of the replayed step live in the graph's pool
         self.optim.sync_lr()
+        self.optim.new_capture_staging()             # (an earlier graph keeps re-reading ITS gradient addresses from its own)
         graph = torch.cuda.CUDAGraph()
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if quiet is not None:      # AccumulateGrad nodes of the eager steps meet the capture stream once: expected here
@@ -138,23 +145,47 @@ class GraphedStep:
         (``load_state_dict``: ClipAdamW drops its tables) invalidate it -- warm up and capture again."""
         return self.optim._e3d_tab is not self.tab or any(p.data_ptr() != q for p, q in zip(self.params, self.ptrs))
 
+    def _may_capture(self, key):
+        return (self.failed is None and key not in self.graphs and len(self.graphs) < self.MAX_GRAPHS
+                and self.seen.get(key, 0) >= self.warmup)
+
+    def _remember(self, key):
+        self.graphs[key] = dict(graph=self.graph, graph2=getattr(self, "graph2", None), static=self.static, loss=self.loss)
+        self.key = key
+
+    def _select(self, key):
+        """Make the captured step of this signature the current one; False if there is none."""
+        e = self.graphs.get(key)
+        if e is None:
+            return False
+        self.graph, self.static, self.loss, self.key = e["graph"], e["static"], e["loss"], key
+        if e["graph2"] is not None:
+            self.graph2 = e["graph2"]
+        return True
+
+    def _drop_graphs(self):
+        self.graphs, self.seen = {}, {}
+        self.graph = self.key = self.static = self.loss = None
+        if hasattr(self, "graph2"):
+            self.graph2 = None
+
     def step(self, batch, batch_idx=0):
-        """Returns the loss (a device tensor; for a replayed step it is overwritten by the next replay)."""
+        """Returns the loss (a device tensor; for a replayed step it is overwritten by the next replay of its graph)."""
         key = self._signature(batch)
-        if self.graph is not None and self._stale():
-            self.graph, self.key, self.seen = None, None, {}
-        if self.failed is None and self.graph is None and self.seen.get(key, 0) >= self.warmup:
+        if self.graphs and self._stale():
+            self._drop_graphs()
+        if self._may_capture(key):
             try:
                 self._capture(batch)                # (records, does not execute: this batch runs as the first replay below)
-                self.key = key
+                self._remember(key)
             except Exception as e:                  # noqa: BLE001 -- any capture failure: stay eager, say so once
                 self.failed = e
-                self.graph = None
+                self._drop_graphs()
                 import traceback
                 import warnings
                 warnings.warn(f"training step could not be captured in a HIP graph, staying eager: {e!r}\n"
                               + "".join(traceback.format_exc(limit=-6)))
-        if self.graph is not None and key == self.key:
+        if self._select(key):
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self.static[k].copy_(v, non_blocking=True)
@@ -214,6 +245,7 @@ class GraphedDDPStep(GraphedStep):
         torch.cuda.synchronize(dev)
         self.optim.zero_grad(set_to_none=True)
         self.optim.sync_lr()
+        self.optim.new_capture_staging()
         avg = self.avg
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -244,14 +276,15 @@ class GraphedDDPStep(GraphedStep):
 
     def step(self, batch, batch_idx=0):
         key = self._signature(batch)
-        if self.graph is not None and self._stale():
-            self.graph, self.graph2, self.key, self.seen = None, None, None, {}
-        if self.failed is None and self.graph is None and self.seen.get(key, 0) >= self.warmup:
+        if self.graphs and self._stale():
+            self._drop_graphs()
+        if self._may_capture(key):
             try:
                 self._capture(batch)
-                self.key = key
+                self._remember(key)
             except Exception as e:                  # noqa: BLE001 -- any capture failure: stay eager, say so once
-                self.failed, self.graph, self.graph2 = e, None, None
+                self.failed = e
+                self._drop_graphs()
                 import traceback
                 import warnings
                 warnings.warn(f"data-parallel training step could not be captured in HIP graphs, staying eager: {e!r}\n"
@@ -259,7 +292,7 @@ class GraphedDDPStep(GraphedStep):
         cur = torch.cuda.current_stream(self.stream.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            if self.graph is not None and key == self.key:
+            if self._select(key):
                 for k, v in batch.items():
                     if torch.is_tensor(v):
                         self.static[k].copy_(v, non_blocking=True)
@@ -277,6 +310,39 @@ class GraphedDDPStep(GraphedStep):
         cur.wait_stream(self.stream)
         loss.record_stream(cur)
         return loss
+
+
+# the tensors of a dataset.py batch that are laid out [B, L, ...] over the ligand / the pocket frame
+# (structure_model/dataset.py:119-162, sequence_model/dataset.py: the same names)
+LIGAND_FRAME_KEYS = ("ligand_angles", "ligand_attn_mask", "ligand_seq", "known_noise", "noised_ligand_angle")
+RECEPTOR_FRAME_KEYS = ("receptor_angles", "receptor_attn_mask", "receptor_seq")
+TRIM_TRAIN = os.environ.get("E3D_TRAIN_TRIM", "0") == "1"            # default of fit(trim_padding=None)
+
+
+def trimmed_frame(batch, multiple=32):
+    """(ligand rows, pocket rows) that cover every valid position of the batch, rounded up to the attention tile."""
+    from .structure_model.sample import trimmed_length
+    return (trimmed_length(batch["ligand_attn_mask"], multiple), trimmed_length(batch["receptor_attn_mask"], multiple))
+
+
+def trim_batch(batch, frame=None, multiple=32):
+    """The batch on the frame of its longest ligand / pocket (``frame``: rows agreed on elsewhere, e.g. across ranks).
+
+    dataset.py pads every item to ``max_seq_len`` = 128 rows; BioLiP ligands are 5-30 residues, so 3 of the decoder's 4
+    attention tiles -- and 3/4 of the rows of every decoder GEMM, LayerNorm and activation -- are padding.  Padding cannot
+    reach a valid position in the forward pass (its keys carry the -10000 bias, whose softmax weight underflows to exactly
+    0.0f; every other op is row-wise) and receives exactly zero gradient in the backward pass (the losses are means over
+    valid positions), so loss and parameter gradients of the trimmed batch are those of the padded one up to the order of
+    the fp32 sums (tests/test_training_gpu.py::test_trimmed_*).  What changes: draws made per frame position inside the
+    step (dropout, PeptideDiff.apply_aa_noise) come from a different place of the random stream."""
+    Ll, Lr = frame if frame is not None else trimmed_frame(batch, multiple)
+    out = dict(batch)
+    for keys, n in ((LIGAND_FRAME_KEYS, Ll), (RECEPTOR_FRAME_KEYS, Lr)):
+        for k in keys:
+            v = out.get(k)
+            if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] > n:
+                out[k] = v[:, :n].contiguous()
+    return out
 
 
 def move_batch(batch, device):
@@ -312,17 +378,21 @@ DEFER_WEIGHT_GRADS = os.environ.get("E3D_DEFER_WGRAD", "1") == "1"   # autograd.
 
 def fit(model, train_loader, val_loader=None, *, max_epochs, min_epochs=0, gradient_clip=1.0, device="cuda:0",
         log_every_n_steps=30, checkpoint_path="./best_val_model.pt", checkpoint_mode="max", max_steps=None,
-        log=print):
+        log=print, trim_padding=None):
     """Returns a history dict.  ``model`` provides training_step / validation_step /
-    configure_optimizers (the reference's LightningModule surface)."""
+    configure_optimizers (the reference's LightningModule surface).
+    ``trim_padding`` (None: E3D_TRAIN_TRIM, default off = the reference's padded frames): run every training and
+    validation step on the frame of the batch's longest ligand / pocket (``trim_batch``; under a process group the frame
+    is the maximum over the ranks, agreed on the host, so that every rank replays the same kind of step)."""
     with ops.arithmetic(TRAIN_ARITHMETIC):
         return _fit(model, train_loader, val_loader, max_epochs=max_epochs, min_epochs=min_epochs, gradient_clip=gradient_clip,
                     device=device, log_every_n_steps=log_every_n_steps, checkpoint_path=checkpoint_path,
-                    checkpoint_mode=checkpoint_mode, max_steps=max_steps, log=log)
+                    checkpoint_mode=checkpoint_mode, max_steps=max_steps, log=log,
+                    trim_padding=TRIM_TRAIN if trim_padding is None else bool(trim_padding))
 
 
 def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_clip, device, log_every_n_steps, checkpoint_path,
-         checkpoint_mode, max_steps, log):
+         checkpoint_mode, max_steps, log, trim_padding=False):
     rank, world, _ = sharding.init_distributed()
     model.to(device)
     sharding.broadcast_parameters(model, src=0)
@@ -349,6 +419,8 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             train_loader.sampler.set_epoch(epoch)
         losses = []
         for batch_idx, batch in enumerate(train_loader):
+            if trim_padding:                         # (on the loader's host tensors: no device round trip)
+                batch = trim_batch(batch, sharding.max_over_ranks_host(trimmed_frame(batch)) if world > 1 else None)
             batch = move_batch(batch, device)
             if stepper is not None:
                 loss = stepper.step(batch, batch_idx)
@@ -396,6 +468,8 @@ def _fit(model, train_loader, val_loader, *, max_epochs, min_epochs, gradient_cl
             vals = []
             with torch.no_grad():
                 for batch_idx, batch in enumerate(val_loader):
+                    if trim_padding:
+                        batch = trim_batch(batch)
                     out = model.validation_step(move_batch(batch, device), batch_idx)
                     vals.append(float(out["val_loss"] if isinstance(out, dict) else out))
             val = sum(vals) / max(1, len(vals)) if vals else math.nan

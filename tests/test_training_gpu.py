@@ -455,3 +455,124 @@ def test_captured_step_reads_no_memory_it_does_not_own(pkg, hip):
         norm = float(optim.last_norm)
     assert 0.1 * sane < norm < 10 * sane, (sane, norm)
     assert all(bool((t == 1.2345e30).all()) for t in held)        # and it wrote into none of them
+
+
+def _grads_of(model, loss_fn):
+    from e3diff_amd import autograd
+    for p in model.parameters():
+        p.grad = None
+    loss = loss_fn()
+    with autograd.deferred_weight_grads():
+        loss.backward()
+    return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _assert_same_gradients(ga, gb, tol):
+    assert set(ga) == set(gb)
+    # relative to each gradient's largest element (not below 1e-4 of the largest gradient element of the model); the key
+    # biases' gradients are zero in exact arithmetic (softmax ignores a shift of all scores of a row): rounding noise, kept apart
+    top = max(float(g.abs().max()) for g in ga.values())
+    noise = [n for n in ga if n.endswith("key.bias")]
+    assert all(float(g[n].abs().max()) < 1e-3 * top for n in noise for g in (ga, gb)), "key-bias gradients are rounding noise"
+    worst = max((float((ga[n] - gb[n]).abs().max()) / max(float(ga[n].abs().max()), 1e-4 * top), n) for n in ga if n not in noise)
+    assert worst[0] < tol, worst
+
+
+@pytest.mark.parametrize("rec_hi", [30, 64])   # pockets within one attention tile / over the whole 64-row frame
+def test_trimmed_structure_batch_has_the_padded_batchs_loss_and_gradients(pkg, hip, rec_hi):
+    """training.trim_batch: the step on the frame of the batch's longest ligand / pocket -- padding can neither reach a valid
+    position in the forward pass nor receive a gradient -- gives the loss and EVERY parameter gradient of the padded step up
+    to the order of the fp32 sums (other GEMM tile shapes at M/2 or M/4 rows; relative to each gradient's largest element)."""
+    from helpers import synthetic_pockets
+    from e3diff_amd import ops, training
+    from e3diff_amd.structure_model.dataset import noise_batch_on_device
+    from e3diff_amd.structure_model.utils import CosineTables
+    model = _small_structure_model()
+    pk = {k: v.to("cuda:0") for k, v in synthetic_pockets(8, 64, seed=21, rec_range=(20, rec_hi)).items() if torch.is_tensor(v)}
+    g = torch.Generator().manual_seed(7)
+    batch = dict(pk, **noise_batch_on_device(pk["ligand_angles"], CosineTables(100), timestep=torch.randint(0, 100, (8, 1), generator=g).to("cuda:0"),
+                                             noise=torch.randn(8, 64, 8, generator=g).to("cuda:0")))
+    small = training.trim_batch(batch)
+    assert small["noised_ligand_angle"].shape[1] == 32 and small["known_noise"].shape[1] == 32
+    assert small["receptor_seq"].shape[1] == (32 if rec_hi <= 32 else 64) and small["timestep"].shape == batch["timestep"].shape
+    with ops.arithmetic("bf16x3"):
+        la, ga = _grads_of(model, lambda: model.training_step(batch))
+        lb, gb = _grads_of(model, lambda: model.training_step(small))
+    assert abs(la - lb) <= 2e-6 * abs(la), (la, lb)
+    _assert_same_gradients(ga, gb, 2e-4)
+
+
+def test_trimmed_sequence_batch_has_the_padded_batchs_loss_and_gradients(pkg, hip):
+    """... and PeptideDiff.get_loss on given timesteps and noised residues (training_step draws them per frame position:
+    another place of the random stream on another frame, the same distribution)."""
+    from helpers import synthetic_pockets
+    from e3diff_amd import ops, training
+    from e3diff_amd.bert import BertConfig
+    from e3diff_amd.sequence_model.model import PeptideDiff
+    c = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=2, max_position_embeddings=64,
+             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    model = PeptideDiff(BertConfig(**c), BertConfig(**c, is_decoder=True, add_cross_attention=True), feature_names=list("ACDEFGHIKLMNPQRSTVWY"),
+                        loss_func=torch.nn.CrossEntropyLoss(), noise_schedule="cosine", timesteps=50, l2_lambda=0.1, lr=1e-4).train().to("cuda:0")
+    batch = {k: v.to("cuda:0") for k, v in synthetic_pockets(8, 64, seed=5, with_ligand_seq=True, rec_range=(20, 30)).items() if torch.is_tensor(v)}
+    g = torch.Generator().manual_seed(11)
+    t_int = torch.randint(1, 51, (8, 1), generator=g).float().to("cuda:0")
+    with ops.arithmetic("bf16x3"):
+        noised = model.apply_aa_noise(batch["ligand_seq"], t_int, u=torch.rand(8, 64, generator=g).to("cuda:0"))
+        small = training.trim_batch(dict(batch, noised=noised))
+        assert small["ligand_seq"].shape[1] == 32 and small["receptor_angles"].shape[1] == 32
+        la, ga = _grads_of(model, lambda: model.get_loss(batch, t_int / 50, noised)[0])
+        lb, gb = _grads_of(model, lambda: model.get_loss(small, t_int / 50, noised[:, :32].contiguous())[0])
+    assert abs(la - lb) <= 2e-6 * abs(la), (la, lb)
+    _assert_same_gradients(ga, gb, 2e-4)
+
+
+def test_graphed_step_keeps_one_graph_per_trimmed_frame(pkg, hip):
+    """Trimmed batches come in a few frames: GraphedStep captures one graph per batch signature (own pool, own gradient
+    tensors, own staging buffer for their addresses) and replays whichever the batch needs -- 12 steps alternating between two
+    frames against eager steps on a twin model: the same losses, the same parameters, two graphs, no eager step after warm-up."""
+    from helpers import synthetic_pockets
+    from e3diff_amd import autograd, ops, training
+    from e3diff_amd.structure_model.dataset import noise_batch_on_device
+    from e3diff_amd.structure_model.utils import CosineTables
+    tab = CosineTables(100)
+    batches = []
+    for i in range(12):
+        pk = {k: v.to("cuda:0") for k, v in synthetic_pockets(8, 64, seed=40 + i, rec_range=(20, 30 if i % 2 else 64)).items()
+              if torch.is_tensor(v)}
+        pk["receptor_attn_mask"][0, : (30 if i % 2 else 64)] = 1.0            # the frame of the batch is 32 / 64 rows for certain
+        g = torch.Generator().manual_seed(900 + i)
+        b = dict(pk, **noise_batch_on_device(pk["ligand_angles"], tab, timestep=torch.randint(0, 100, (8, 1), generator=g).to("cuda:0"),
+                                             noise=torch.randn(8, 64, 8, generator=g).to("cuda:0")))
+        batches.append(training.trim_batch(b))
+    assert {b["receptor_seq"].shape[1] for b in batches} == {32, 64} and {b["known_noise"].shape[1] for b in batches} == {32}
+    results = []
+    for graphed in (False, True):
+        model = _small_structure_model()
+        optim = model.configure_optimizers()["optimizer"]
+        params = [p for p in model.parameters() if p.requires_grad]
+        stepper = training.GraphedStep(model, optim, params, 1.0) if graphed else None
+        losses = []
+        with ops.arithmetic("bf16x3"):
+            for k, batch in enumerate(batches):
+                optim.param_groups[0]["lr"] = 1e-3 * (1 + 0.1 * k)
+                if graphed:
+                    losses.append(float(stepper.step(batch)))
+                    assert float(optim.last_norm) < 1e3, (k, float(optim.last_norm))
+                else:
+                    loss = model.training_step(batch)
+                    optim.zero_grad(set_to_none=True)
+                    with autograd.deferred_weight_grads():
+                        loss.backward()
+                    training.clip_and_step(params, optim, 1.0)
+                    losses.append(float(loss))
+        if graphed:
+            assert stepper.failed is None and len(stepper.graphs) == 2 and all(n == 2 for n in stepper.seen.values()), stepper.seen
+        assert {int(st["step"]) for st in optim.state.values()} == {12}
+        results.append((losses, [p.detach().clone() for p in params]))
+    (la, pa), (lb, pb) = results
+    assert all(abs(a - b) <= 2e-5 * abs(a) for a, b in zip(la, lb)), (la, lb)
+    p0 = [p.detach().clone() for p in _small_structure_model().parameters() if p.requires_grad]
+    moved = sum(float((a - z).abs().sum()) for a, z in zip(pa, p0))
+    apart = sum(float((a - b).abs().sum()) for a, b in zip(pa, pb))
+    assert moved > 0 and apart < 0.02 * moved, (apart, moved)

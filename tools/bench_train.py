@@ -24,11 +24,12 @@ DEV = "cuda:0"
 
 
 def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, warmup=2, device=DEV, ddp=False, layers=None,
-        seed=0, arithmetic=None, graph=None):
+        seed=0, arithmetic=None, graph=None, trim=False):
     """One GPU's training step of BASELINE config 2 (structure, B=32) / config 4 (sequence, B=64): forward + loss +
     backward + gradient-norm clip + fused AdamW on synthetic BioLiP-shaped batches.  Returns a dict.
     ``ddp``: the step of ``training.fit`` under an initialised process group (BASELINE config 4: one rank per GPU,
-    per-rank batch 64) -- weights broadcast from rank 0, gradients as views of the all-reduce buckets, the buckets sent
+    per-rank batch 64; ``trim``: the same batch on the frame of its longest ligand / pocket, ``training.trim_batch``)
+    -- weights broadcast from rank 0, gradients as views of the all-reduce buckets, the buckets sent
     (RCCL; gloo in rehearsals) while the deferred weight-gradient launches of the later layers still run; timed between
     barriers, max over ranks by the caller."""
     DEV = device   # noqa: N806 (shadows the module default)
@@ -54,6 +55,13 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
     optim = model.configure_optimizers()["optimizer"]
     params = [p for p in model.parameters() if p.requires_grad]
     pk = {k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=seed, with_ligand_seq=True).items() if torch.is_tensor(v)}
+    frame = (L, L)
+    if trim:
+        frame = pkg.training.trimmed_frame(pk)
+        if ddp:
+            from e3diff_amd import sharding as _sh
+            frame = _sh.max_over_ranks_host(frame)
+        pk = pkg.training.trim_batch(pk, frame)
     averager = None
     if ddp:
         import torch.distributed as dist
@@ -128,7 +136,7 @@ def run(model_name="structure", batch=None, seq_len=128, steps=8, dropout=0.0, w
             ws = [t.cpu() for t in ws]
         dist.all_gather(ws, w)
         assert all(float(t) == float(ws[0]) for t in ws), "ranks diverged"
-    return {"model": model_name, "batch": B, "seq_len": L, "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
+    return {"model": model_name, "batch": B, "seq_len": L, "frame": list(frame), "layers": layers, "params_M": sum(p.numel() for p in params) / 1e6,
             "arithmetic": mode, "dropout": dropout, "graph_replay": bool(stepper is not None and stepper.graph is not None),
             "ms_per_step": dt * 1e3, "samples_per_s": B / dt, "host_enqueue_ms": host_ms,
             **({"ranks": dist.get_world_size(), "global_batch": B * dist.get_world_size(),
@@ -147,10 +155,11 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.0, help="hidden and attention-probability dropout (reference: 0.1)")
     ap.add_argument("--eager", action="store_true", help="no HIP-graph replay of the step")
     ap.add_argument("--arithmetic", default=None, help="bf16x3 (default) | bf16x6 | bf16 = plain bf16 products, the reference's own training precision")
+    ap.add_argument("--trim", action="store_true", help="the batch on the frame of its longest ligand / pocket (training.trim_batch)")
     args = ap.parse_args()
     r = run(args.model, args.batch, args.seq_len, args.steps, args.dropout, arithmetic=args.arithmetic,
-            graph=False if args.eager else None)
-    print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} layers={r['layers']} params={r['params_M']:.1f}M "
+            graph=False if args.eager else None, trim=args.trim)
+    print(f"{r['model']} training step: B={r['batch']} L={r['seq_len']} frame={r['frame'][0]}x{r['frame'][1]} layers={r['layers']} params={r['params_M']:.1f}M "
           f"gemm_mode={r['arithmetic']} dropout={r['dropout']} graph={r['graph_replay']}: {r['ms_per_step']:.1f} ms/step = {r['samples_per_s']:.1f} samples/s "
           f"(loss {r['loss']:.4f}, peak mem {r['peak_mem_GiB']:.1f} GiB; host enqueue {r['host_enqueue_ms']:.1f} ms)", flush=True)
 
