@@ -517,11 +517,14 @@ def main():
             out["train"] = {"structure_B32_L128": bench_train.run("structure", steps=10),
                             "sequence_B64_L128": bench_train.run("sequence", steps=10),
                             "structure_B32_L128_eager": bench_train.run("structure", steps=5, graph=False),
+                            "structure_B32_L128_trimmed": bench_train.run("structure", steps=10, trim=True),
+                            "sequence_B64_L128_trimmed": bench_train.run("sequence", steps=10, trim=True),
                             "note": "forward + loss + backward + grad-norm clip + AdamW, 12+12 / 6 layers x 768, synthetic "
                                     "batches, dropout 0 (the reference's 0.1 costs +0.7 ms); the step as training.fit runs it "
                                     "for one process: captured into a HIP graph after two eager steps and replayed "
                                     "(graph_replay; host_enqueue_ms = Python time per step); *_eager = the same step "
-                                    "launch by launch"}
+                                    "launch by launch; *_trimmed = the same batches on the frame of their longest ligand / "
+                                    "pocket (training.fit(trim_padding=True), opt-in: same loss and gradients, `frame` rows)"}
             import bench_single
             # BASELINE configs[0] on the GPU: ONE 64-residue pocket, 50 reverse steps (latency, not throughput)
             out["single_pocket"] = bench_single.run(seq_len=64, batch=1, steps=50)

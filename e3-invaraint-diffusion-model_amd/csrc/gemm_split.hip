@@ -53,6 +53,15 @@ __device__ __forceinline__ f32x16 mma16(const f16x8 a, const f16x8 b, const f32x
 struct Epi { float* absmax; float scale; };
 
 constexpr int BN = 128, BK = 32;
+#ifdef GEMM_STAMPS   // lab builds only (tools/lab/gemm_stamps.py): s_memtime stamps of waves 0 and 4 of ONE workgroup of the general kernel
+__device__ long long gemm_stamps[2][64][8];
+#define GSTAMP(slot)                                                                                                    \
+    do {                                                                                                                \
+        if (stamp_on && kt < 64 && lane == 0) gemm_stamps[wid >> 2][kt][(slot)] = __builtin_readcyclecounter();         \
+    } while (0)
+#else
+#define GSTAMP(slot) do {} while (0)
+#endif
 #ifndef E3D_GEMM_FRAG_PREFETCH
 #define E3D_GEMM_FRAG_PREFETCH 1
 #endif
@@ -367,8 +376,12 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     // kt + 2, issued an iteration ago) are still in flight.  With one set (rounds 1-2) a load had to arrive within ONE
     // k-step: at M = 4096 the k-step was its latency (the same launch with a third of the MFMAs, terms = 1, was only 10 %
     // faster), i.e. a CU never had more than ~32 KB in flight.
+#ifdef GEMM_STAMPS
+    const bool stamp_on = bx == GEMM_STAMPS && by == 0 && (wid & 3) == 0;
+#endif
     auto k_step = [&](int kt, f32x4 (&xa)[NA_], f32x4 (&xb)[NB_]) {
         const bool more = kt + 1 < nk;
+        GSTAMP(0);
         if (!PIPE && more) {
             sa.load(xa, k_begin + (kt + 1) * BK, K);
             sb.load(xb, k_begin + (kt + 1) * BK, K);
@@ -394,6 +407,9 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
                 for (int n = 0; n < TN; ++n)
                     fb2[ks][s][n] = *reinterpret_cast<const typename Vec<E>::x8*>(bb + s * B_BYTES + swz_off(b_row + 32 * n, 2 * ks + half));
             }
+#ifdef GEMM_STAMPS
+        if (PREF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); GSTAMP(1); }
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             typename Vec<E>::x8 fa[NS][2], fb[NS][TN];
@@ -447,8 +463,14 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);   // keep the staging slices where they were put
             }
         }
+        GSTAMP(2);
         if (PIPE) {
+#ifdef GEMM_STAMPS
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (what the barrier waits for anyway is told apart from the barrier)
+            GSTAMP(3);
+#endif
             __syncthreads();
+            GSTAMP(4);
             cur ^= 1;
         } else {
             __syncthreads();  // everyone done reading the single buffer
@@ -1168,6 +1190,10 @@ int dispatch(int act, bool a_kmaj, bool b_kmaj, const float* A, int64_t lda, con
 }
 
 }  // namespace
+
+#ifdef GEMM_STAMPS
+extern "C" int e3d_debug_gemm_stamps(long long* t) { return (int)hipMemcpyFromSymbol(t, HIP_SYMBOL(gemm_stamps), sizeof(long long) * 2 * 64 * 8); }
+#endif
 
 #ifdef E3D_STAMPS
 extern "C" int e3d_debug_read_stamps(long long* host_out) {

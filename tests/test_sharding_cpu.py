@@ -31,6 +31,14 @@ def _worker(rank, world, port, q):
     gathered = S.gather_in_rank_order(local)
     assert gathered == [f"pocket{i}" for i in range(7)], gathered
     assert S.max_over_ranks(1.0 + rank) == float(world)
+    # the frame of a trimmed training batch, agreed on the host (training.fit(trim_padding=True) under a process group)
+    assert S.max_over_ranks_host((32 + 32 * rank, 96 - 32 * rank)) == (64, 96)
+    from e3diff_amd import training as T
+    m = (torch.arange(128)[None, :] < torch.tensor([[5 + 40 * rank], [17]])).float()
+    b = {"ligand_attn_mask": m, "ligand_angles": torch.zeros(2, 128, 8), "receptor_attn_mask": torch.ones(2, 128),
+         "receptor_seq": torch.zeros(2, 128, 20), "timestep": torch.zeros(2, 1)}
+    t = T.trim_batch(b, S.max_over_ranks_host(T.trimmed_frame(b)))
+    assert t["ligand_angles"].shape == (2, 64, 8) and t["receptor_seq"].shape == (2, 128, 20) and t["timestep"].shape == (2, 1)
 
     # ---- training: averaged grads == mean over ranks; a never-used parameter stays in sync
     torch.manual_seed(0)

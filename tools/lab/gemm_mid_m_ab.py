@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Lab: the forward GEMM at M = 512 ... 2048 (a decoder on trimmed frames: 32 x 32 rows): skinny split-K kernel against the
+general kernel's tile forms 1-4, one process, interleaved rounds, hot operands (judge the winner in the step as well)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__  # noqa: E402
+
+pkg = __graft_entry__.load_package()
+ops, lib = pkg.ops, pkg.hip.lib()
+DEV = "cuda:0"
+variants = ["skinny", 0, 1, 2, 3, 4]
+
+
+def run(v, fn):
+    ops.SKINNY_MAX_M = 1024 if v == "skinny" else 0
+    ops.SKINNY_MAX_TILES = 1 << 30 if v == "skinny" else 768
+    lib.e3d_gemm_general_select(0 if v == "skinny" else v)
+    return fn()
+
+
+for M in [int(x) for x in os.environ.get("MS", "512,1024,2048").split(",")]:
+    for N, K in ((768, 768), (2304, 768), (768, 1024), (1024, 768)):
+        a = torch.randn(M, K, device=DEV)
+        w = torch.randn(N, K, device=DEV) / K ** 0.5
+        b = torch.randn(N, device=DEV)
+        fn = lambda: ops.gemm(a, w, b, mode="bf16x3")   # noqa: E731
+        times = {v: [] for v in variants}
+        for rnd in range(7):
+            for v in variants:
+                if v == "skinny" and M > 1024:
+                    continue
+                run(v, fn)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    run(v, fn)
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / 20)
+        print(f"M={M:5d} N={N:4d} K={K:4d}: " + "  ".join(f"{v}: {sorted(t)[len(t) // 2] * 1e3:6.1f} us" for v, t in times.items() if t), flush=True)
