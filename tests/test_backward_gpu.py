@@ -140,6 +140,57 @@ def test_ragged_weight_gradients_of_mixed_shapes_in_one_launch(pkg, hip, mode, t
                 assert rel_err(outs[0][count + p], want_b.float()) < 1e-5, (M, p)
 
 
+@pytest.mark.parametrize("pattern", ["ligand", "pocket", "all_dead", "first_dead", "columns"])
+def test_weight_gradients_of_batches_whose_padded_gradient_rows_are_zero(pkg, hip, pattern):
+    """The weight-gradient launches on dz as a training step produces it -- rows of padded positions exactly zero, whole
+    32-token k-tiles of them (3 of 4 in a ligand frame), leading ones, all of them, or zero only in one tile row of output
+    workgroups -- against fp64, the grouped (ragged) launch and the per-layer split-K launch.  (A form of the kernel body
+    that skips the MFMAs of such k-tiles was built and measured in round 4: -11 % at 3/4 dead tiles, +6..15 % on live ones,
+    nothing on the step -- the k-step of this layout is bound by its staging, profiles/r04_wgrad_dead_tile_skip_ab.log.)"""
+    import ctypes
+    lib = pkg.hip.lib()
+    terms = pkg.ops.GEMM_MODES["bf16x3"]
+    B, L = 6, 128
+    M = B * L
+    shapes = [(768, 768, 2304), (1024, 768, 1024), (300, 160, 304)]
+    count = len(shapes)
+    tok = torch.arange(M)
+    if pattern == "ligand":
+        lens = torch.tensor([5, 30, 17, 31, 1, 32])
+    elif pattern == "pocket":
+        lens = torch.tensor([20, 128, 64, 65, 97, 33])
+    elif pattern == "all_dead":
+        lens = torch.zeros(B, dtype=torch.long)
+    elif pattern == "first_dead":
+        lens = torch.tensor([0, 0, 128, 0, 40, 0])
+    else:
+        lens = torch.full((B,), L)
+    valid = ((tok % L) < lens[tok // L]).float()[:, None]
+    wide = [torch.randn(M, ld, generator=g(10 + p)) * valid for p, (N, K, ld) in enumerate(shapes)]
+    if pattern == "columns":
+        wide[0][:, :256] *= ((tok % L) < 20).float()[:, None]
+    x = [torch.randn(M, K, generator=g(100 + p)).to(DEV) for p, (N, K, ld) in enumerate(shapes)]
+    dz = [w.to(DEV)[:, :N] for w, (N, K, ld) in zip(wide, shapes)]
+    dw = [torch.full((N, K), 7.0, device=DEV) for (N, K, ld) in shapes]
+    db = [torch.full((N,), 7.0, device=DEV) for (N, K, ld) in shapes]
+    arr = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])   # noqa: E731
+    ints = lambda vals, ty: (ty * count)(*vals)   # noqa: E731
+    pkg.hip.check(lib.e3d_gemm_wgrad_ragged_f32_split(
+        arr(dz), arr(x), arr(dw), arr(db), ints([s_[0] for s_ in shapes], ctypes.c_int), ints([s_[1] for s_ in shapes], ctypes.c_int),
+        ints([t.stride(0) for t in dz], ctypes.c_int64), ints([t.stride(0) for t in x], ctypes.c_int64), 0, count, M, terms,
+        torch.cuda.current_stream().cuda_stream), "ragged wgrad")
+    from e3diff_amd.autograd import gemm_general
+    for p, (N, K, ld) in enumerate(shapes):
+        want = wide[p][:, :N].double().t() @ x[p].cpu().double()
+        bound = 1e-4 * float(want.abs().max())          # (all_dead: exact zeros asked for)
+        assert float((dw[p].cpu().double() - want).abs().max()) <= bound, (pattern, p)
+        want_b = wide[p][:, :N].double().sum(0)
+        assert float((db[p].cpu().double() - want_b).abs().max()) <= 1e-5 * float(want_b.abs().max()), (pattern, p)
+        if ld % 4 == 0 and N % 4 == 0:
+            got = gemm_general(dz[p], True, x[p], True, N, K, M, mode="bf16x3")
+            assert float((got.cpu().double() - want).abs().max()) <= bound, (pattern, p)
+
+
 def test_gemm_general_odd_reduction_and_strided(pkg, hip):
     from e3diff_amd.autograd import gemm_general
     M, N, K = 70, 200, 45          # K-major operands: any K, any N
