@@ -341,7 +341,8 @@ extern "C" int64_t e3d_relkey_attn_bwd_workspace_floats(int B, int nh, int Lq, i
     const int64_t part = relkey ? (int64_t)B * nh * q_tiles * (k_tiles + 1) * 32 * D : 0;
     // [P | dS] of the two-launch kernels; the fused kernel parks the distance-table planes in the same region
     const int64_t head = relkey ? (e3d_attn_bwd_coop_scratch_bytes(Lk) + 3) / 4 : 0;
-    return (2 * pm > head ? 2 * pm : head) + part + (relkey ? e3d_attn_bwd_coop_de_floats(Lq, Lk) : 0);
+    // (+ one liveness word per (b, head, query tile) of the fused kernel: after the chunk sums)
+    return (2 * pm > head ? 2 * pm : head) + part + (relkey ? e3d_attn_bwd_coop_de_floats(Lq, Lk) + (int64_t)B * nh * q_tiles : 0);
 }
 
 extern "C" int e3d_relkey_attn_bwd_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,

@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
     const float* __restrict__ v, int64_t v_bs, int64_t v_rs, const bf16x8* __restrict__ e_row, const bf16x8* __restrict__ e_tr,
     int P, const float* __restrict__ key_mask, const float* __restrict__ dout, const float* __restrict__ outp,
     const float* __restrict__ lse, float* __restrict__ dq, int64_t dq_bs, int64_t dq_rs, float* __restrict__ dk,
-    int64_t dk_bs, int64_t dk_rs, float* __restrict__ dv, int64_t dv_bs, int64_t dv_rs, float* __restrict__ dE_part, int nh,
-    int Lq, int Lk, E3dDrop drop_in) {
+    int64_t dk_bs, int64_t dk_rs, float* __restrict__ dv, int64_t dv_bs, int64_t dv_rs, float* __restrict__ dE_part, int* __restrict__ unit_live,
+    int nh, int Lq, int Lk, E3dDrop drop_in) {
     const E3dDrop drop = e3d_drop_resolve(drop_in);   // + the device-side epoch (graph replays: e3d_common.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* img0 = smem_raw;               // phase A: Q      phase B: K
@@ -456,11 +456,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_coop_kernel(
         }
         float* part_base = RELKEY ? dE_part + ((int64_t)bh * q_tiles + qt) * (k_tiles + 1) * 32 * D : nullptr;
         BSTAMP(3);
+        // (dE blocks of a dead query tile are neither written nor read: de_chunk_sum_kernel looks at unit_live)
+        if (RELKEY && lane == 0) unit_live[bh * q_tiles + qt] = q_live[qt];
         if (!q_live[qt]) {                         // (wave-uniform) dO of this wave's query tile is all zeros: dQ = 0, dE blocks = 0
-            if (RELKEY) {
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                for (int i = lane; i < (k_tiles + 1) * 32 * D / 4; i += 64) reinterpret_cast<f32x4*>(part_base)[i] = z4;
-            }
             if (q_ok) store_rows_T(dq0, dq1, dq + b * dq_bs + (int64_t)qrow * dq_rs + h * D, half);
 #ifdef BWD_STAMPS
             BSTAMP(4); BSTAMP(5); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BSTAMP(6);
@@ -635,13 +633,17 @@ constexpr int DE_CHUNKS = 12;   // (b, head) chunks of the dE reduction's first 
 // 256-byte row per unit and E row at a stride of 40 KB -- 36 us for 63 MB at B=32, L=128 -- and ends in float atomics).
 // Stage 1: block (slab = (qt, j), chunk c) sums slab (qt, j) -- 32 x 64 floats, contiguous 8 KB per unit -- over the
 // (b, head) units of chunk c, in unit order: every load is a coalesced 16-byte piece of an 8-KB run.
+// Units whose query tile saw an all-zero dO (``unit_live`` = 0, written by the fused kernel) hold no blocks: skipped.
 __global__ __launch_bounds__(256) void de_chunk_sum_kernel(const float* __restrict__ part, float* __restrict__ chunk_sums,
-                                                           int slabs, int n_bh, int bh_per_chunk) {
+                                                           const int* __restrict__ unit_live, int slabs, int slabs_per_qt,
+                                                           int n_bh, int bh_per_chunk) {
     const int slab = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     const int b0 = c * bh_per_chunk, b1 = min(n_bh, b0 + bh_per_chunk);
+    const int qt = slab / slabs_per_qt, q_tiles = slabs / slabs_per_qt;
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
     const float* p = part + ((int64_t)b0 * slabs + slab) * 2048 + 4 * tid;
     for (int bh = b0; bh < b1; ++bh, p += (int64_t)slabs * 2048) {
+        if (unit_live[bh * q_tiles + qt] == 0) continue;     // (workgroup-uniform)
         a0 += *reinterpret_cast<const f32x4*>(p);
         a1 += *reinterpret_cast<const f32x4*>(p + 1024);
     }
@@ -705,13 +707,17 @@ int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const f
     bf16x8* e_tr = e_row ? e_row + n_items : nullptr;
     if (dist_emb)
         hipLaunchKernelGGL(e_planes_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb, e_row, e_tr, P, J0, n_items);
+    // liveness words of the (b, head, query tile) units: after the chunk sums (e3d_relkey_attn_bwd_workspace_floats)
+    int* unit_live = dist_emb ? reinterpret_cast<int*>(part + (int64_t)B * nh * ((Lq + 31) / 32) * ((Lk + 31) / 32 + 1) * 2048 +
+                                                       e3d_attn_bwd_coop_de_floats(Lq, Lk))
+                              : nullptr;
     static std::atomic<uint64_t> ok[4];
 #define E3D_BWD_COOP(RK, DR)                                                                                               \
     do {                                                                                                                   \
         e3d_allow_lds(ok[2 * RK + DR], attn_bwd_coop_kernel<RK, DR>, LDS_BYTES);                                           \
         hipLaunchKernelGGL((attn_bwd_coop_kernel<RK, DR>), dim3(B * nh, 2), dim3(256), LDS_BYTES, s, q, q_bs, q_rs, k, k_bs, \
                            k_rs, v, v_bs, v_rs, e_row, e_tr, P, key_mask, dout, out, lse, dq, dq_bs, dq_rs, dk, dk_bs,      \
-                           dk_rs, dv, dv_bs, dv_rs, part, nh, Lq, Lk, drop);                                               \
+                           dk_rs, dv, dv_bs, dv_rs, part, unit_live, nh, Lq, Lk, drop);                                    \
     } while (0)
     if (dist_emb) {
         if (dropping) E3D_BWD_COOP(true, true);
@@ -725,7 +731,8 @@ int e3d_attn_bwd_coop_launch(const float* q, int64_t q_bs, int64_t q_rs, const f
         const int q_tiles = (Lq + 31) / 32, k_tiles = (Lk + 31) / 32, slabs = q_tiles * (k_tiles + 1), n_bh = B * nh;
         const int per = (n_bh + DE_CHUNKS - 1) / DE_CHUNKS, n_chunks = (n_bh + per - 1) / per;
         float* chunk_sums = part + (int64_t)n_bh * slabs * 2048;
-        hipLaunchKernelGGL(de_chunk_sum_kernel, dim3(slabs, n_chunks), dim3(256), 0, s, part, chunk_sums, slabs, n_bh, per);
+        hipLaunchKernelGGL(de_chunk_sum_kernel, dim3(slabs, n_chunks), dim3(256), 0, s, part, chunk_sums, unit_live, slabs,
+                           k_tiles + 1, n_bh, per);
         hipLaunchKernelGGL(de_final_sum_kernel, dim3(2 * P - 1), dim3(64), 0, s, chunk_sums, d_dist_emb, P, q_tiles, k_tiles,
                            n_chunks);
     }
