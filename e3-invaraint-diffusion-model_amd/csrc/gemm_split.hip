@@ -94,7 +94,10 @@ __device__ __forceinline__ void split4<2, _Float16>(const f32x4 v, f16x4 (&parts
 }
 
 // One operand's staging: NV float4-equivalents (4 consecutive k of one row) per thread.
-template <int ROWS, bool KMAJ, int NT = 512>
+#ifndef GEMM_LAB_RAW   // timing-only lab builds (results are garbage): bit 1 = operand A, bit 2 = operand B of the K-contiguous
+#define GEMM_LAB_RAW 0  // layouts staged WITHOUT the fp32 -> two-term split (what pre-split operand planes would cost the k-step)
+#endif
+template <int ROWS, bool KMAJ, int NT = 512, bool RAW = false>
 struct Stager {
     static constexpr int NV = ROWS * 8 / NT;   // items per thread (512 threads: A 4, B 2)
     const float* src[NV];   // K-contiguous: the item's row base;  K-major: the operand base (uniform)
@@ -157,7 +160,13 @@ struct Stager {
             for (int j = 0; j < 4; ++j) v[j] = k0 + kbase[i] + j < K ? v[j] : 0.f;
         }
         typename Vec<E>::x4 p[NS];
-        split4<NS, E>(v, p);
+        if constexpr (RAW && NS == 2) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            p[0] = __builtin_bit_cast(typename Vec<E>::x4, f32x2_{v[0], v[1]});
+            p[1] = __builtin_bit_cast(typename Vec<E>::x4, f32x2_{v[2], v[3]});
+        } else {
+            split4<NS, E>(v, p);
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<typename Vec<E>::x4*>(img + s * part_bytes + off[i]) = p[s];
     }
@@ -306,8 +315,8 @@ __device__ __forceinline__ void gemm_split_body(unsigned char* smem_raw, const f
     const int l31 = lane & 31, half = lane >> 5;
 
     static_assert(!TR || (A_KMAJ && B_KMAJ), "the transposing staging exists for the K-major x K-major layout");
-    typedef typename std::conditional<TR, StagerT<BM, NT>, Stager<BM, A_KMAJ, NT>>::type SA;
-    typedef typename std::conditional<TR, StagerT<BN, NT>, Stager<BN, B_KMAJ, NT>>::type SB;
+    typedef typename std::conditional<TR, StagerT<BM, NT>, Stager<BM, A_KMAJ, NT, (GEMM_LAB_RAW & 1) && !A_KMAJ && !B_KMAJ>>::type SA;
+    typedef typename std::conditional<TR, StagerT<BN, NT>, Stager<BN, B_KMAJ, NT, (GEMM_LAB_RAW & 2) && !A_KMAJ && !B_KMAJ>>::type SB;
     SA sa;
     SB sb;
     sa.init(A, lda, row0, M, tid);
