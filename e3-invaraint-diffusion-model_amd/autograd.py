@@ -324,16 +324,18 @@ def layernorm_bwd(dy, s, gamma, eps, want_affine_grads=True, drop=None):
     M, H = s.shape
     ds = torch.empty_like(s)
     dg = db = None
-    if want_affine_grads:      # one allocation: the C side then zeroes both with one fill
+    ws, n_ws = None, 0
+    if want_affine_grads:      # dgamma | dbeta in one allocation; per-block partial sums meet in ``ws`` (no atomics, no zero-fill)
         both = torch.empty((2, H), device=s.device, dtype=torch.float32)
         dg, db = both[0], both[1]
+        n_ws = hip.lib().e3d_layernorm_bwd_workspace_floats(M, H)
+        ws = torch.empty((n_ws,), device=s.device, dtype=torch.float32)
+    dsd = torch.empty_like(s) if drop is not None else None
+    p, seed = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+    hip.check(hip.lib().e3d_layernorm_bwd_ws(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dsd), _p(dg), _p(db), M, H, p, seed,
+                                             _p(ws), n_ws, _stream()), "e3d_layernorm_bwd_ws")
     if drop is not None:
-        dsd = torch.empty_like(s)
-        hip.check(hip.lib().e3d_layernorm_bwd_drop(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dsd), _p(dg), _p(db), M, H,
-                                                   float(drop[0]), int(drop[1]), _stream()), "e3d_layernorm_bwd_drop")
         return ds, dg, db, dsd
-    hip.check(hip.lib().e3d_layernorm_bwd(_p(dy), _p(s), _p(gamma), eps, _p(ds), _p(dg), _p(db), M, H, _stream()),
-              "e3d_layernorm_bwd")
     return ds, dg, db
 
 

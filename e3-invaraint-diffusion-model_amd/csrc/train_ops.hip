@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, float eps,
                                                             float* __restrict__ ds, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int M, float* __restrict__ dsd = nullptr,
-                                                            E3dDrop drop_in = E3dDrop{}) {
+                                                            E3dDrop drop_in = E3dDrop{}, float* __restrict__ part = nullptr) {
     constexpr int H = 256 * V;
     const int lane = threadIdx.x & 63;
     const E3dDrop drop = DROP ? e3d_drop_resolve(drop_in) : drop_in;
@@ -138,7 +138,41 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int c = threadIdx.x; c < 2 * H; c += 256) {
         const int which = c / H, col = c - which * H;
         float* dst = which ? dbeta : dgamma;
-        if (dst) atomicAdd(dst + col, red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col]);
+        const float v = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+        // ``part`` (the _ws entry points): the block's sums go to row blockIdx.x of a [blocks][2 H] workspace and
+        // ln_param_grad_sum_kernel adds the rows up in a fixed order -- no zero-fill launch, no atomics (256-512 adders per
+        // address were ~9 us of a 15-us launch at M = 4096: twice the blocks cost +9 us per launch in the training step)
+        if (part) part[(int64_t)blockIdx.x * 2 * H + c] = v;
+        else if (dst) atomicAdd(dst + col, v);
+    }
+}
+
+// dgamma | dbeta [2 H] = column sums of the per-block partial rows [n_part][2 H] (fixed order: deterministic).  64 columns x 16
+// row slices per block: a thread's <= 32 rows are independent loads, 8 in flight.
+__global__ __launch_bounds__(1024) void ln_param_grad_sum_kernel(const float* __restrict__ part, int n_part, int H2,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int H) {
+    const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, sl = threadIdx.x >> 6;
+    __shared__ float red[16][64];
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    if (c < H2) {
+        for (int r0 = sl; r0 < n_part; r0 += 128) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 16 * u;
+                if (r < n_part) a[u] += part[(int64_t)r * H2 + c];
+            }
+        }
+    }
+    red[sl][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (sl == 0 && c < H2) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][cl];
+        float* dst = c < H ? dgamma : dbeta;
+        if (dst) dst[c < H ? c : c - H] = v;
     }
 }
 
@@ -410,6 +444,36 @@ extern "C" int e3d_layernorm_bwd(const float* dy, const float* s, const float* g
     DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, s,
                                      gamma, eps, ds, dgamma, dbeta, M));
     return e3d_launch_status("e3d_layernorm_bwd");
+}
+
+static int ln_bwd_blocks(int M) { return (M + 15) / 16 < 512 ? (M + 15) / 16 : 512; }
+
+extern "C" int64_t e3d_layernorm_bwd_workspace_floats(int M, int H) { return (M <= 0 || H <= 0) ? -1 : (int64_t)ln_bwd_blocks(M) * 2 * H; }
+
+// As e3d_layernorm_bwd / e3d_layernorm_bwd_drop (ds_dropped == NULL: no dropout), with the parameter gradients summed through
+// ``workspace`` (e3d_layernorm_bwd_workspace_floats(M, H) floats) instead of atomics on a zeroed output: deterministic.
+extern "C" int e3d_layernorm_bwd_ws(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
+                                    float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, float* workspace,
+                                    int64_t workspace_floats, void* stream) {
+    E3D_REQUIRE(dy && s && ds && M > 0, "layernorm_bwd_ws: bad arguments");
+    E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (ds_dropped || drop_p == 0.f), "layernorm_bwd_ws: p = %f", (double)drop_p);
+    const bool affine = dgamma || dbeta;
+    const int blocks = ln_bwd_blocks(M);
+    E3D_REQUIRE(!affine || (workspace && workspace_floats >= (int64_t)blocks * 2 * H),
+                "layernorm_bwd_ws: workspace of %lld floats, %lld needed", (long long)workspace_floats, (long long)blocks * 2 * H);
+    float* part = affine ? workspace : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    if (ds_dropped) {
+        const E3dDrop d = e3d_drop_make(drop_p, drop_seed);
+        DISPATCH_V(H, hipLaunchKernelGGL((layernorm_bwd_kernel<V, true>), dim3(blocks), dim3(256), 0, st, dy, s, gamma, eps, ds,
+                                         dgamma, dbeta, M, ds_dropped, d, part));
+    } else {
+        DISPATCH_V(H, hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, s, gamma, eps, ds, dgamma,
+                                         dbeta, M, (float*)nullptr, E3dDrop{}, part));
+    }
+    if (affine)
+        hipLaunchKernelGGL(ln_param_grad_sum_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, st, part, blocks, 2 * H, dgamma, dbeta, H);
+    return e3d_launch_status("e3d_layernorm_bwd_ws");
 }
 
 extern "C" int e3d_layernorm_bwd_drop(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,

@@ -75,6 +75,8 @@ _SIGNATURES = {
                                        _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_uint64, _P]),
     "e3d_attn_dropout_mask": (c_int, [c_int, c_int, c_int, c_int, c_float, c_uint64, _P, _P]),
     "e3d_layernorm_bwd": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, _P]),
+    "e3d_layernorm_bwd_workspace_floats": (c_int64, [c_int, c_int]),
+    "e3d_layernorm_bwd_ws": (c_int, [_P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_float, c_uint64, _P, c_int64, _P]),
     "e3d_adaln_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, _P]),
     "e3d_act_fwd": (c_int, [_P, c_int, _P, c_int64, _P]),
     "e3d_act_bwd": (c_int, [_P, _P, c_int, _P, c_int64, _P]),

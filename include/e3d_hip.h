@@ -399,6 +399,15 @@ int e3d_residual_layernorm_drop_fwd(const float* x, const float* residual, const
                                     float* s_out, float* out, int M, int H, float drop_p, uint64_t drop_seed, void* stream);
 int e3d_layernorm_bwd_drop(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
                            float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, void* stream);
+/* Both of the above in one entry point (ds_dropped == NULL: no dropout) with the parameter gradients summed through a caller
+ * workspace of e3d_layernorm_bwd_workspace_floats(M, H) floats -- per-block partial rows, added up in a fixed order by a second
+ * launch -- instead of float atomics on a zero-filled output: deterministic, and what autograd.layernorm_bwd calls (round 4:
+ * 256-512 adders per address were most of the launch).  Backward of torch.nn.LayerNorm in BertSelfOutput / BertOutput
+ * (transformers 4.38.2 modeling_bert.py) and SELayer.norm1 / norm2 (structure_model/model.py:27-67). */
+int64_t e3d_layernorm_bwd_workspace_floats(int M, int H);
+int e3d_layernorm_bwd_ws(const float* dy, const float* s, const float* gamma, float eps, float* ds, float* ds_dropped,
+                         float* dgamma, float* dbeta, int M, int H, float drop_p, uint64_t drop_seed, float* workspace,
+                         int64_t workspace_floats, void* stream);
 
 /* ---- row-complete GEMM + bias + residual + LayerNorm (ABI v4; inference at large M) ----------------------------------
  * BertSelfOutput / BertOutput whole -- LayerNorm(dense(x) + residual), transformers 4.38.2 modeling_bert.py, reached through
