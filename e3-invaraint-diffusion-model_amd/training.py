@@ -150,7 +150,8 @@ class GraphedStep:
                 and self.seen.get(key, 0) >= self.warmup)
 
     def _remember(self, key):
-        self.graphs[key] = dict(graph=self.graph, graph2=getattr(self, "graph2", None), static=self.static, loss=self.loss)
+        self.graphs[key] = dict(graph=self.graph, graph2=getattr(self, "graph2", None), static=self.static, loss=self.loss,
+                                grads=[p.grad for p in self.params])
         self.key = key
 
     def _select(self, key):
@@ -158,6 +159,9 @@ class GraphedStep:
         e = self.graphs.get(key)
         if e is None:
             return False
+        if self.params[0].grad is not e["grads"][0]:   # ``p.grad`` shows the gradients of the step that ran last
+            for p, g in zip(self.params, e["grads"]):
+                p.grad = g
         self.graph, self.static, self.loss, self.key = e["graph"], e["static"], e["loss"], key
         if e["graph2"] is not None:
             self.graph2 = e["graph2"]

@@ -559,6 +559,9 @@ def test_graphed_step_keeps_one_graph_per_trimmed_frame(pkg, hip):
                 if graphed:
                     losses.append(float(stepper.step(batch)))
                     assert float(optim.last_norm) < 1e3, (k, float(optim.last_norm))
+                    # ``p.grad`` is the gradient of the step that just ran, whichever graph replayed it
+                    seen_norm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None))
+                    assert abs(float(seen_norm) - float(optim.last_norm)) <= 1e-4 * float(optim.last_norm), (k, float(seen_norm))
                 else:
                     loss = model.training_step(batch)
                     optim.zero_grad(set_to_none=True)

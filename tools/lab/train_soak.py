@@ -37,7 +37,13 @@ optim = model.configure_optimizers()["optimizer"]
 params = [p for p in model.parameters() if p.requires_grad]
 eager = os.environ.get("E3D_SOAK_EAGER") == "1"
 stepper = training.GraphedStep(model, optim, params, 1.0, warmup=10 ** 9 if eager else 2)
-pool = [{k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=s, with_ligand_seq=True).items() if torch.is_tensor(v)} for s in range(8)]
+trim = os.environ.get("E3D_SOAK_TRIM") == "1"      # batches on the frame of their longest ligand / pocket: several graphs
+pool = [{k: v.to(DEV) for k, v in synthetic_pockets(B, L, seed=s, with_ligand_seq=True,
+                                                    rec_range=(20, (40, 70, 100, None)[s % 4]) if trim else (20, None)).items()
+         if torch.is_tensor(v)} for s in range(8)]
+if trim:
+    pool = [training.trim_batch(b) for b in pool]
+    print("frames (ligand x pocket rows):", sorted({(b["ligand_angles"].shape[1], b["receptor_angles"].shape[1]) for b in pool}))
 losses, norms = [], []
 trace = [int(v) for v in os.environ.get("E3D_SOAK_TRACE", "").split(":")] if os.environ.get("E3D_SOAK_TRACE") else None
 t0 = time.perf_counter()
@@ -70,7 +76,8 @@ dt = time.perf_counter() - t0
 ls = torch.stack(losses).double().cpu()
 assert bool(torch.isfinite(ls).all()), "non-finite loss"
 w = max(10, steps // 8)
-print(f"{name}: {steps} steps in {dt:.1f} s ({dt / steps * 1e3:.1f} ms/step incl. batch prep), replaying={stepper.graph is not None}, failed={stepper.failed!r}")
+print(f"{name}: {steps} steps in {dt:.1f} s ({dt / steps * 1e3:.1f} ms/step incl. batch prep), replaying={stepper.graph is not None}, "
+      f"graphs={len(stepper.graphs)}, eager steps per signature={sorted(stepper.seen.values())}, failed={stepper.failed!r}")
 ns = torch.stack(norms).double().cpu()
 bad = (~torch.isfinite(ns)).nonzero().flatten().tolist()
 print("   first non-finite gradient norms at steps:", bad[:8], "of", len(bad))
