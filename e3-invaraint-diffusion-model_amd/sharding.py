@@ -178,6 +178,7 @@ class GradientAverager:
     def all_reduce_flats(self):
         """Sum every bucket over the ranks (the division by the world size belongs to the caller's captured segment);
         asynchronous on the wire, in bucket order, joined before returning to the caller's stream."""
+        self._order_for_host_backend(self._flat[0])
         works = [dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True) for i in range(len(self.buckets))]
         for w in works:
             w.wait()
@@ -205,7 +206,17 @@ class GradientAverager:
         post-accumulate-grad hook never fires for them."""
         self._on_grad(p)
 
+    @staticmethod
+    def _order_for_host_backend(flat):
+        """gloo on GPU tensors (the one-card rehearsals; production is RCCL): its device-to-host copy runs on a pool stream that
+        waits for an event recorded on the caller's stream -- and was seen reading a bucket before the gradient kernels queued
+        ahead of that event had finished (ROCm 7.2, torch 2.10: ranks 1e-5 apart after a few steps, tools/lab/ddp_second_run_diff.py;
+        gone with this wait).  So the host waits for the caller's stream first.  Costs the rehearsal its overlap, nothing else."""
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            torch.cuda.current_stream(flat.device).synchronize()
+
     def _launch(self, i):
+        self._order_for_host_backend(self._flat[i])
         self._handles[i] = dist.all_reduce(self._flat[i], op=dist.ReduceOp.SUM, async_op=True)
 
     def average(self):
@@ -235,6 +246,7 @@ class GradientAverager:
                 else:
                     dst.copy_(p.grad.reshape(-1))
                 off += p.numel()
+            self._order_for_host_backend(flat)
             handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
         for work, flat, bucket in handles:     # buckets overlap each other on the wire
             work.wait()

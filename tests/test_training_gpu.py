@@ -104,18 +104,18 @@ def test_bench_two_rank_rehearsal_reports_the_data_parallel_training_leg():
 def test_two_rank_rehearsal_of_the_data_parallel_step_on_trimmed_frames():
     """Two ranks on cuda:0 over gloo (tools/lab/ddp_trim_check.py under torch.distributed.run): the ranks' batches differ, the
     frame is the maximum over the ranks (training.trim_batch, sharding.max_over_ranks_host), both replay the graph-segment
-    step, and their weights are identical afterwards (bench_train's check).  ONE run per process: a second data-parallel
-    training in the same process is a known gap."""
+    step, and their weights are identical afterwards (bench_train's check) -- twice in one process: the second run is the one
+    that exposed gloo's unordered device-to-host copy (sharding.GradientAverager._order_for_host_backend)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29641", os.path.join(root, "tools", "lab", "ddp_trim_check.py"), "1"],
+                        "--master-port", "29641", os.path.join(root, "tools", "lab", "ddp_trim_check.py"), "1", "1"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("run 0")]
-    assert line and "ok frame=[32, " in line[0] and "graph=True" in line[0], r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("run ")]
+    assert len(lines) == 2 and all("ok frame=[32, " in ln and "graph=True" in ln for ln in lines), r.stdout[-2000:]
 
 
 def test_data_parallel_step_runs_on_rccl_with_a_group_of_one():

@@ -35,6 +35,8 @@ for run in range(runs):
     sharding.broadcast_parameters(model, src=0)
     avg = sharding.GradientAverager(model.parameters(), overlap=os.environ.get("OVERLAP", "1") == "1")
     stepper = training.GraphedDDPStep(model, optim, params, 1.0, avg, warmup=(2 if mode == "graph" else 10 ** 9))
+    if rank == 0:
+        print(f"   run {run}: stepper stream {stepper.stream.cuda_stream:#x}", flush=True)
     with ops.arithmetic("bf16x3"):
         for k in range(10):
             stepper.step(pk)
