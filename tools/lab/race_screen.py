@@ -65,16 +65,22 @@ for (B, L) in ((256, 256), (512, 128), (64, 256)):
 # every gradient bit-identical between two launches (no atomics anywhere in that path now) and block-wise against the
 # exact-fp32 two-launch kernels; with and without the bounds / skip, with and without dropout
 from e3diff_amd.autograd import functional as F  # noqa: E402
-for (B, L, relkey, drop) in ((32, 128, True, 0.0), (32, 128, False, 0.0), (64, 96, True, 0.0), (32, 128, True, 0.1), (48, 33, True, 0.0)):
+# round 4: ... and with dO rows of padded positions zero and ligand-sized masks (dead query tiles, all-zero probability tiles and
+# the per-unit liveness words of the dE reduction are then in play: ``short``)
+for (B, L, relkey, drop, short) in ((32, 128, True, 0.0, False), (32, 128, False, 0.0, False), (64, 96, True, 0.0, False),
+                                    (32, 128, True, 0.1, False), (48, 33, True, 0.0, False), (32, 128, True, 0.0, True),
+                                    (32, 128, False, 0.0, True), (64, 128, True, 0.1, True)):
     nh, H = 12, 768
     worst = 0.0
     for r in range(max(1, reps // 2)):
         g = torch.Generator(device=dev).manual_seed(31 * r + L)
         qkv0 = torch.randn(B * L, 3 * H, device=dev, generator=g)
         E0 = torch.randn(2 * L - 1, 64, device=dev, generator=g)
-        lens = torch.randint(1, L + 1, (B,), device=dev, generator=g)
+        lens = torch.randint(1, (31 if short else L) + 1, (B,), device=dev, generator=g)
         mask = (torch.arange(L, device=dev)[None] < lens[:, None]).float()
         go = torch.randn(B * L, H, device=dev, generator=g)
+        if short:
+            go = go * mask.reshape(-1, 1)
 
         def grads(mode):
             qkv = qkv0.clone().requires_grad_(True)
@@ -97,7 +103,7 @@ for (B, L, relkey, drop) in ((32, 128, True, 0.0), (32, 128, False, 0.0), (64, 9
             if err > 2e-4 or not bool(torch.isfinite(x).all()):
                 bad += 1
                 print(f"attention backward B={B} L={L} relkey={relkey} rep {r}: error {err:.2e}", flush=True)
-    print(f"attention backward (fused) B={B} L={L} relkey={relkey} drop={drop}: worst error vs the fp32-grade kernels {worst:.2e}", flush=True)
+    print(f"attention backward (fused) B={B} L={L} relkey={relkey} drop={drop}{' zero dO rows at padding, lengths 1-31' if short else ''}: worst error vs the fp32-grade kernels {worst:.2e}", flush=True)
 # round 3: the grouped weight-gradient launches with the transposing staging (float4 loads, [k][row] images, two staging
 # register sets, ds_read_b64_tr_b16 fragments): bit-identical between two launches, block-wise against fp64
 import ctypes  # noqa: E402
