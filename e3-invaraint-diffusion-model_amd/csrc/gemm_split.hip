@@ -1100,13 +1100,18 @@ int launch(const float* A, int64_t lda, const float* B, int64_t ldb, const float
         // workgroup per CU (measured at K = 768: ~25 us and ~38 us per round; form 3 at M = 4096: N = 768 26.8 us
         // against 32.5 (4-wave 128x128) / 36.9, N = 2304 70 against 81; M = 8192: form 1 by 4 %)
         else form = 25 * ((g128 + cus - 1) / cus) <= 38 * ((g256 + cus - 1) / cus) ? 3 : 1;
+        // small launches of the forward layout (M <= 2048 rows, N <= 1024: a decoder on trimmed frames, a few pockets): 128x64
+        // tiles on four waves, up to three workgroups per CU with barriers of their own -- 18.8 against 22.4 us at M = 1024, N = K =
+        // 768, 19.6 against 22.8 at N = 1024, 19.7 against 23.0 at M = 2048 (profiles/r04_gemm_mid_m_ab.log); in the step:
+        // profiles/r04_gemm_form4_small_m_in_step.log.  (At M = 4096 and above the same form changed nothing in the step: below.)
+        if (NS == 2 && !A_KMAJ && !B_KMAJ && M <= 2048 && N <= 1024) form = 4;
     }
     // form 4 (round 4, selectable only: E3D_GEMM_FORM=4 / e3d_gemm_general_select(4)): 128x64 tiles on FOUR waves -- 48 KB of LDS,
     // so up to three workgroups share a CU with barriers of their own.  Standalone (hot operands, tools/lab/gemm_forms_ab.py) a
     // CU carrying 1 / 2 / 3 such workgroups takes ~20 / 28 / 41 us at K = 768 against ~24.5 us per round of 128x128 tiles (M =
     // 2048 x N = 768: 20.1 vs 23.5 us, M = 8192 x N = 768: 42.6 vs 48.1) -- and inside the sequence training step (M = 8192,
     // cold operands, neighbours on the queue) a shape rule built on those figures changed nothing: 19.9 vs 19.9 ms, three
-    // interleaved pairs (profiles/r04_gemm_form4_128x64_ab.log).  Not dispatched by shape.
+    // interleaved pairs (profiles/r04_gemm_form4_128x64_ab.log).  Dispatched by shape only for M <= 2048 (above).
     if constexpr (NS == 2 && !A_KMAJ && !B_KMAJ) {
         if (form == 4) return launch_general<NS, ACT, A_KMAJ, B_KMAJ, 2, 2, E, 1>(A, lda, B, ldb, bias, out, ldc, M, N, K, epi, s);
     }

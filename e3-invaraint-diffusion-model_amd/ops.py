@@ -242,6 +242,10 @@ def f16_weight(weight):
 # against 24.2; beyond that the tiled kernels (a 24-step k chain, ~24 us) are faster (M = 512 x N = 2304: 33 vs 24.5).
 # E3D_GEMM_SKINNY=0 disables the path (A/B timing).
 SKINNY_MAX_M = 1024 if os.environ.get("E3D_GEMM_SKINNY", "1") == "1" else 0
+# plain GEMMs (no fused LayerNorm finish) above this many rows take the general kernel's 128x64 four-wave form instead (round 4:
+# 18.8 / 23.0 / 19.4 us against 21.6 / 27.1 / 27.5 skinny at M = 1024 for (N, K) = (768, 768) / (768, 1024) / (1024, 768);
+# at M = 512 the skinny kernels win two of the three: profiles/r04_gemm_mid_m_ab.log)
+SKINNY_GEMM_MAX_M = int(os.environ.get("E3D_GEMM_SKINNY_MAX_M", "512"))
 SKINNY_MAX_TILES = 768
 _SKINNY_WS = {}
 _SKINNY_RETIRED = []
@@ -287,7 +291,7 @@ def gemm(a, weight, bias=None, act=ACT_NONE, out=None, mode=None, absmax=None, p
     if terms == 19 and prescale:
         weight, scale = f16_weight(weight)
     with _timed("gemm", (M, N, K, act)):
-        if _skinny_ok(terms, M, N, K, a) and out.stride(0) % 4 == 0:
+        if _skinny_ok(terms, M, N, K, a) and out.stride(0) % 4 == 0 and M <= min(SKINNY_MAX_M, SKINNY_GEMM_MAX_M):
             ws = _skinny_workspace(a.device, M, N, K)
             hip.check(hip.lib().e3d_gemm_skinny_f32_split_ex(_p(a), a.stride(0), _p(weight), _p(bias), _p(out), out.stride(0),
                                                              M, N, K, act, terms, _p(ws), ws.numel(), _p(absmax), scale, _stream()),

@@ -18,6 +18,7 @@ variants = ["skinny", 0, 1, 2, 3, 4]
 
 def run(v, fn):
     ops.SKINNY_MAX_M = 1024 if v == "skinny" else 0
+    ops.SKINNY_GEMM_MAX_M = 1024
     ops.SKINNY_MAX_TILES = 1 << 30 if v == "skinny" else 768
     lib.e3d_gemm_general_select(0 if v == "skinny" else v)
     return fn()
