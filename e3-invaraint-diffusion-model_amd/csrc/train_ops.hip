@@ -324,12 +324,18 @@ __global__ __launch_bounds__(256) void small_k_wgrad_kernel(const float* __restr
     // time (independent 256-byte loads), the four waves' partials meet in LDS and leave as ONE atomic per output word
     // and block.  (History: one thread per column over 64 rows, 21 atomics per thread -- 2 M float atomics onto 16 K
     // addresses were the kernel: 114 us at M = 8192, H = 768, F = 20.)
-    __shared__ float xs[256 * 32];
+    __shared__ __attribute__((aligned(16))) float xs[256 * 32];
     __shared__ float red[4][33][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     const int m0 = blockIdx.y * rows_per_block, rows = min(M, m0 + rows_per_block) - m0;
-    for (int i = threadIdx.x; i < rows * F; i += 256) xs[i] = x[(int64_t)m0 * F + i];
+    // x rows padded to 32 floats in LDS (zeros past F): the inner loop is then 8 broadcast 16-byte reads and 32 FMAs per row
+    // without a branch per feature (round 4: the F-dependent `if` inside the unrolled loop was a scalar branch per feature and
+    // row -- 63 us at M = 8192, H = 768, F = 20 for 25 MB of g)
+    for (int i = threadIdx.x; i < rows * 32; i += 256) {
+        const int r = i >> 5, f = i & 31;
+        xs[i] = f < F ? x[(int64_t)(m0 + r) * F + f] : 0.f;
+    }
     __syncthreads();
     float acc[32];
 #pragma unroll
@@ -343,10 +349,13 @@ __global__ __launch_bounds__(256) void small_k_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             accb += gv[j];
-            const float* xr = xs + min(m + 4 * j, rows - 1) * F;
+            const f32x4* xr = reinterpret_cast<const f32x4*>(xs + min(m + 4 * j, rows - 1) * 32);
 #pragma unroll
-            for (int f = 0; f < 32; ++f)
-                if (f < F) acc[f] = fmaf(gv[j], xr[f], acc[f]);
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 xv = xr[q];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[4 * q + t] = fmaf(gv[j], xv[t], acc[4 * q + t]);
+            }
         }
     }
 #pragma unroll
