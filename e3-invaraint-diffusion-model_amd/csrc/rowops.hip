@@ -300,8 +300,12 @@ extern "C" int e3d_embed_layernorm_fwd(const float* x, int F, const float* W, co
                                          gamma, beta, eps, post_add, rows_per_add, z_out, out, M));
         return e3d_launch_status("e3d_embed_layernorm_fwd");
     }
-    // every workgroup re-stages W^T (F*H*4 bytes of LDS): cap the grid so each one amortises it over >= 32 rows
-    int blocks = (M + 127) / 128;
+    // every workgroup re-stages W^T (F*H*4 bytes of LDS): each one amortises it over >= 32 rows, and a launch that does not
+    // fill the chip at 128 rows per workgroup spreads out first (round 4: M = 8192 ran on 64 CUs -- 59 us in the training
+    // steps; 32 rows per workgroup = 256 workgroups; M = 65 536 keeps its 512 x 128 rows)
+    int rpb = (M + 255) / 256;
+    rpb = rpb < 32 ? 32 : (rpb > 128 ? 128 : rpb);
+    int blocks = (M + rpb - 1) / rpb;
     blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     const dim3 grid(blocks), block(256);
     const size_t lds = (size_t)F * H * sizeof(float);
