@@ -469,7 +469,9 @@ class _Linear(torch.autograd.Function):
         N = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if K % 128 == 0 and N % 32 == 0 and M >= 1024:
+            # (few rows against a large weight -- the adaLN modulation of the per-item conditioning, M = batch size, W [6 H, H] --
+            #  also go through W^T: the K-major read of W took 141 us per step there, the skinny kernel on W^T ~10)
+            if K % 128 == 0 and N % 32 == 0 and (M >= 1024 or N * K >= (1 << 21)):
                 dx = ops.gemm(dz, _transposed_weight(weight), None)      # dz [M,N] . (W^T [K,N])^T
             else:
                 dx = gemm_general(dz, False, weight, True, M, K, N)      # dz [M,N] . W[N,K]
