@@ -129,21 +129,26 @@ __device__ __forceinline__ X8 tr_read8(const unsigned char* lo4, const unsigned 
 // fully coalesced 1-KB reads instead of 8 reads of 64 scattered 16-byte pieces (measured: 17 % of the kernel).
 // Rows outside [0, 2P-2] (never paired with a valid (query, key)) are clamped.
 template <typename E>
+// ``e_absmax`` (or NULL): raised to the largest |element| of the rows read here -- every row the attention kernels can pair
+// with a valid (query, key) -- so that the bound of the padded-tile skip costs no launch of its own (round 4).
 __global__ __launch_bounds__(256) void e_fragments_kernel(const float* __restrict__ e, typename AV<E>::x8* __restrict__ frag,
-                                                          int P, int J0, int n_items) {
+                                                          int P, int J0, int n_items, float* __restrict__ e_absmax) {
     const int i = blockIdx.x * 256 + threadIdx.x;   // item = ((j * 2 + plane) * 4 + kb) * 64 + lane
-    if (i >= n_items) return;
+    if (i >= n_items) return;                       // (n_items is a multiple of 512: whole workgroups)
     const int lane = i & 63, kb = (i >> 6) & 3, plane = (i >> 8) & 1, j = i >> 9;
     const int row = min(max(P + 32 * (j - J0) + (lane & 31), 0), 2 * P - 2);
     const float* src = e + row * D + 16 * kb + 8 * (lane >> 5);
     typename AV<E>::x8 out;
+    unsigned amax = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const float v = src[t];
         const E hi = (E)v;
         out[t] = plane ? (E)(v - (float)hi) : hi;
+        e3d_absmax_accum(amax, v);
     }
     frag[i] = out;
+    if (e_absmax && plane == 0) e3d_absmax_commit(amax, e_absmax, lane);   // (plane is uniform per wave: i >> 8)
 }
 
 // (the timing-only ablation switches of round 4 -- no loads / no ring / no MFMAs ... -- live in
@@ -603,7 +608,7 @@ static int coop_launch_t(const float* q, int64_t q_bs, int64_t q_rs, const float
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
     if (!e_ready)   // e_ready: the caller kept the planes of this (dist_emb, Lk, terms) from an earlier call
         hipLaunchKernelGGL(e_fragments_kernel<E>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
-                           reinterpret_cast<typename AV<E>::x8*>(e_scratch), P, J0, n_items);
+                           reinterpret_cast<typename AV<E>::x8*>(e_scratch), P, J0, n_items, (float*)nullptr);
     return launch_any<true, E>(W, q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, e_scratch, P, key_mask, out, lse, B, nh, Lq,
                                Lk, q_tiles, skip, bnd, drop, dropping, s);
 }
@@ -636,14 +641,14 @@ extern "C" int e3d_debug_read_attn_stamps(long long* host_out) {
 #endif
 
 // the pre-pass alone: fragment-order planes of dist_emb for key length Lk into ``scratch``
-int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, hipStream_t s) {
+int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, float* e_absmax, hipStream_t s) {
     const int J0 = (Lk + 31) / 32, n_items = 2 * J0 * 512;
     if (f16)
         hipLaunchKernelGGL(e_fragments_kernel<_Float16>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
-                           reinterpret_cast<f16x8*>(scratch), P, J0, n_items);
+                           reinterpret_cast<f16x8*>(scratch), P, J0, n_items, e_absmax);
     else
         hipLaunchKernelGGL(e_fragments_kernel<__bf16>, dim3((n_items + 255) / 256), dim3(256), 0, s, dist_emb,
-                           reinterpret_cast<bf16x8*>(scratch), P, J0, n_items);
+                           reinterpret_cast<bf16x8*>(scratch), P, J0, n_items, e_absmax);
     return e3d_launch_status("e3d_relkey_attn_fwd_split (distance-table planes)");
 }
 

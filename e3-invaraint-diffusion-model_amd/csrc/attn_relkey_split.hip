@@ -367,7 +367,7 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
                                             const float* dist_emb, int P, const float* key_mask, float* out,
                                             float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                             uint64_t drop_seed, void* e_scratch, int e_scratch_ready, const float* q_absmax,
-                                            const float* k_absmax, const float* e_absmax, void* stream) {
+                                            const float* k_absmax, float* e_absmax, void* stream) {
     const E3dBounds bnd{q_absmax, k_absmax, dist_emb ? e_absmax : nullptr};
     E3D_REQUIRE(!dist_emb || !q_absmax || e_absmax, "attn_split: rel-key attention with element bounds needs e_absmax too");
     E3D_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attn_split: drop_p=%g outside [0, 1)", (double)drop_p);
@@ -389,7 +389,7 @@ extern "C" int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_
     hipStream_t s = (hipStream_t)stream;
     if (dist_emb && e_scratch && !e_scratch_ready) {
         // whichever kernel serves this call, a scratch handed in is valid afterwards (callers cache it)
-        const int rc = e3d_attn_fill_planes(dist_emb, P, Lk, e_scratch, f16, s);
+        const int rc = e3d_attn_fill_planes(dist_emb, P, Lk, e_scratch, f16, e_absmax, s);   // (also raises *e_absmax)
         if (rc) return rc;
         e_scratch_ready = 1;
     }

@@ -220,7 +220,7 @@ __device__ __forceinline__ uint64_t e3d_attn_drop_idx4(int bh, int Lq, int Lk, i
     return ((uint64_t)bh * Lq + q) * (uint64_t)((Lk + 3) >> 2) + (uint64_t)(key0 >> 2);
 }
 
-int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, hipStream_t s);
+int e3d_attn_fill_planes(const float* dist_emb, int P, int Lk, void* scratch, int f16, float* e_absmax, hipStream_t s);
 
 // attn_relkey_coop.hip: workgroup-cooperative bf16x3 / f16x3 attention forward (internal; arguments validated by the
 // caller); ``dropping``: dropout on the probabilities (bf16x3 only)

@@ -324,14 +324,17 @@ int e3d_relkey_attn_fwd_split_drop(const float* q, int64_t q_bs, int64_t q_rs, c
  * ``q_absmax`` / ``k_absmax`` / ``e_absmax`` (device, one float each, or NULL): upper bounds of |element| over the
  * call's Q rows, K rows (INCLUDING padded positions) and the distance table (required with dist_emb when the other
  * two are given) -- as left by e3d_gemm_bias_act_f32_split_ex / e3d_absmax_f32.  They only decide whether all-padding
- * key tiles may be skipped (see e3d_attn_skip_padded_tiles); NULL = never skip.  Read on the device: no host sync. */
+ * key tiles may be skipped (see e3d_attn_skip_padded_tiles); NULL = never skip.  Read on the device: no host sync.
+ * When the call writes the planes itself (e_scratch given, e_scratch_ready == 0) it also RAISES *e_absmax to the largest
+ * |element| of the table rows it reads (round 4: the bound costs no launch of its own -- hand in a slot that holds 0 or an
+ * earlier bound; a value that is already larger stays). */
 int64_t e3d_attn_scratch_bytes(int Lk);
 int e3d_relkey_attn_fwd_split_ex(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,
                                  int64_t k_rs, const float* v, int64_t v_bs, int64_t v_rs,
                                  const float* dist_emb, int P, const float* key_mask, float* out,
                                  float* lse, int B, int nh, int Lq, int Lk, int terms, float drop_p,
                                  uint64_t drop_seed, void* e_scratch, int e_scratch_ready, const float* q_absmax,
-                                 const float* k_absmax, const float* e_absmax, void* stream);
+                                 const float* k_absmax, float* e_absmax, void* stream);
 
 /* e3d_relkey_attn_bwd for a forward that used (drop_p, drop_seed). */
 int e3d_relkey_attn_bwd_drop(const float* q, int64_t q_bs, int64_t q_rs, const float* k, int64_t k_bs,

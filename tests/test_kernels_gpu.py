@@ -203,6 +203,20 @@ def test_attention_skips_padded_tiles_only_when_the_bounds_prove_it_exact(pkg, h
     for b in (None, (big, small), (small, big), (nan, small), (small, nan)):
         out = run(b).view(B, L, H)
         assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all(), b   # dense sweep of item 0
+    # the distance table's bound is raised by the call that writes its planes (no launch of its own since round 4): a table
+    # with large elements must switch the skip off although q and k are proven small ...
+    run_e = lambda e, p_: pkg.ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV),  # noqa: E731
+                                            dist_emb=e, max_pos=p_, mode=mode, bounds=(small, small))
+    out = run_e(E * 1.0e3, P).view(B, L, H)
+    assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all()
+    # ... and only the rows a valid (query, key) pair can reach count: max_pos = 2 L, a huge element in a row no pair of an
+    # L-token frame reaches leaves the skip on, the same element inside the window switches it off
+    E2 = torch.randn(4 * L - 1, 64, generator=g(5)).to(DEV)
+    far, near = E2.clone(), E2.clone()
+    far[0, 3] = 1.0e6
+    near[2 * L - 1, 3] = 1.0e6
+    assert torch.isfinite(run_e(far, 2 * L)).all()
+    assert torch.isnan(run_e(near, 2 * L).view(B, L, H)[0]).all()
 
 
 def _attention_case(pkg, B, nh, L, scale, seed, lens):
