@@ -336,9 +336,16 @@ __global__ __launch_bounds__(256) void small_k_wgrad_kernel(const float* __restr
     // x rows padded to 32 floats in LDS (zeros past F): the inner loop is then 8 broadcast 16-byte reads and 32 FMAs per row
     // without a branch per feature (round 4: the F-dependent `if` inside the unrolled loop was a scalar branch per feature and
     // row -- 63 us at M = 8192, H = 768, F = 20 for 25 MB of g)
-    for (int i = threadIdx.x; i < rows * 32; i += 256) {
-        const int r = i >> 5, f = i & 31;
-        xs[i] = f < F ? x[(int64_t)(m0 + r) * F + f] : 0.f;
+    {   // (all 32 loads of a thread in flight: a rolled loop paid one load latency per trip -- most of the kernel's time)
+        const int f = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+        float xv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int r = r0 + 8 * u;
+            xv[u] = (f < F && r < rows) ? x[(int64_t)(m0 + r) * F + f] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) xs[(r0 + 8 * u) * 32 + f] = xv[u];
     }
     __syncthreads();
     float acc[32];
@@ -374,6 +381,91 @@ __global__ __launch_bounds__(256) void small_k_wgrad_kernel(const float* __restr
             if (f < 32) atomicAdd(dW + (transpose_out ? (int64_t)f * H + h : (int64_t)h * F + f), v);
             else if (db) atomicAdd(db + h, v);
         }
+    }
+}
+
+// The same sums for H % 64 == 0 (every model width) with 1-KB loads: a lane takes FOUR consecutive columns (float4) of one of
+// the four rows a wave reads per instruction (lane = 16 row-group + column quad), 4 x 32 accumulators per lane; the four row
+// groups meet through two shuffles per accumulator at the end, the four waves through LDS, the blocks through one atomic per
+// output word as above.  (Round 4: the form above read 256 bytes per load instruction and took 53 us for 25 MB of g at
+// M = 8192, H = 768 -- latency, not bytes.)
+__global__ __launch_bounds__(256) void small_k_wgrad4_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                             float* __restrict__ dW, float* __restrict__ db, int M, int H, int F,
+                                                             int transpose_out, int rows_per_block) {
+    __shared__ __attribute__((aligned(16))) float xs[256 * 32];
+    __shared__ float red[4][33][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, rg = lane >> 4, c4 = lane & 15;
+    const int h0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * rows_per_block, rows = min(M, m0 + rows_per_block) - m0;
+    {   // (all 32 loads of a thread in flight: a rolled loop paid one load latency per trip -- most of the kernel's time)
+        const int f = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+        float xv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int r = r0 + 8 * u;
+            xv[u] = (f < F && r < rows) ? x[(int64_t)(m0 + r) * F + f] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) xs[(r0 + 8 * u) * 32 + f] = xv[u];
+    }
+    __syncthreads();
+    float acc[4][32], accb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        accb[c] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) acc[c][f] = 0.f;
+    }
+    const float* gp = g + (int64_t)m0 * H + h0 + 4 * c4;
+    for (int it0 = 0; it0 * 16 < rows; it0 += 4) {
+        f32x4 gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = 16 * (it0 + u) + 4 * w + rg;
+            gv[u] = row < rows ? *reinterpret_cast<const f32x4*>(gp + (int64_t)row * H) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = min(16 * (it0 + u) + 4 * w + rg, rows - 1);
+            const f32x4* xr = reinterpret_cast<const f32x4*>(xs + row * 32);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accb[c] += gv[u][c];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 xv = xr[q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[c][4 * q + t] = fmaf(gv[u][c], xv[t], acc[c][4 * q + t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+            float v = acc[c][f];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (rg == 0) red[w][f][4 * c4 + c] = v;
+        }
+        float b = accb[c];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (rg == 0) red[w][32][4 * c4 + c] = b;
+    }
+    __syncthreads();
+    // one atomic per output word and block, consecutive lanes on consecutive words: dW[h][f] of the block's 64 columns is one
+    // contiguous run of 64 F floats (a lane per column h, as the form above does it, puts the 64 lanes of every atomic
+    // instruction on 64 different cache lines F floats apart -- that, not the loads, was the kernel's time)
+    for (int o = threadIdx.x; o < 64 * F; o += 256) {
+        const int hh = transpose_out ? (o & 63) : o / F, f = transpose_out ? (o >> 6) : o - hh * F;
+        const float v = (red[0][f][hh] + red[1][f][hh]) + (red[2][f][hh] + red[3][f][hh]);
+        atomicAdd(dW + (transpose_out ? (int64_t)f * H + h0 + hh : (int64_t)h0 * F + o), v);
+    }
+    if (db && threadIdx.x < 64) {
+        const int hh = threadIdx.x;
+        atomicAdd(db + h0 + hh, (red[0][32][hh] + red[1][32][hh]) + (red[2][32][hh] + red[3][32][hh]));
     }
 }
 
@@ -581,9 +673,13 @@ extern "C" int e3d_small_k_wgrad(const float* g, const float* x, float* dW, floa
     hipError_t e = e3d_zero_async(dW, (size_t)H * F, s);
     if (e == hipSuccess && db) e = e3d_zero_async(db, (size_t)H, s);
     E3D_REQUIRE(e == hipSuccess, "small_k_wgrad: memset failed: %s", hipGetErrorString(e));
-    const int rpb = 256;   // = the kernel's LDS tile of x rows
-    hipLaunchKernelGGL(small_k_wgrad_kernel, dim3((H + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, g, x, dW, db, M,
-                       H, F, transpose_out, rpb);
+    const int rpb = 256;   // = the kernels' LDS tile of x rows
+    if (H % 64 == 0 && ((uintptr_t)g % 16) == 0)
+        hipLaunchKernelGGL(small_k_wgrad4_kernel, dim3(H / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, g, x, dW, db, M, H, F,
+                           transpose_out, rpb);
+    else
+        hipLaunchKernelGGL(small_k_wgrad_kernel, dim3((H + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, s, g, x, dW, db, M,
+                           H, F, transpose_out, rpb);
     return e3d_launch_status("e3d_small_k_wgrad");
 }
 
