@@ -426,19 +426,22 @@ def attention(q, k, v, B, nh, Lq, Lk, key_mask=None, dist_emb=None, max_pos=0, w
                     # training (weights change every step): a pool slot of the table, raised by this call -- never lowered,
                     # so a value from an earlier step is still a bound; inference keeps a scalar of its own with the planes
                     # (a pool slot would be zeroed by the next chain's reset while the cached planes live on)
-                    # (the call that writes the planes raises the slot it is given to max |table| itself: no launch for it)
+                    # (the call that writes the planes raises the slot it is given to max |table| itself -- no launch for it -- but
+                    #  only a call that carries all three bounds hands the slot over: without them the scalar kept with the cached
+                    #  planes is computed here, so that it is a bound for whichever later call re-uses the planes)
                     e_abs = None
-                    if q_abs is not None and not infer:
+                    have_bounds = q_abs is not None and k_abs is not None
+                    if have_bounds and not infer:
                         try:
                             e_abs = absmax_slot(dist_emb, "e", q.device)
                         except AttributeError:
                             e_abs = torch.zeros(1, device=q.device, dtype=torch.float32)
-                    elif q_abs is not None:
+                    elif have_bounds:
                         e_abs = torch.zeros(1, device=q.device, dtype=torch.float32)
                     if infer and not torch.cuda.is_current_stream_capturing():
                         try:
                             if e_abs is None:
-                                e_abs = torch.zeros(1, device=q.device, dtype=torch.float32)
+                                e_abs = absmax(dist_emb.detach())
                             dist_emb._e3d_planes = (weight_key(dist_emb) + (Lk, terms), scratch, e_abs)
                         except AttributeError:
                             pass

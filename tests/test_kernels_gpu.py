@@ -217,6 +217,16 @@ def test_attention_skips_padded_tiles_only_when_the_bounds_prove_it_exact(pkg, h
     near[2 * L - 1, 3] = 1.0e6
     assert torch.isfinite(run_e(far, 2 * L)).all()
     assert torch.isnan(run_e(near, 2 * L).view(B, L, H)[0]).all()
+    # inference keeps the planes AND the table's bound across calls: a first call without bounds must still leave a valid bound
+    # for a later call that brings them (the planes are then ready: nothing would raise the scalar any more)
+    with torch.no_grad():
+        E3 = E.clone() * 1.0e3
+        first = pkg.ops.attention(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, L, L, key_mask=mask.to(DEV), dist_emb=E3,
+                                  max_pos=P, mode=mode)
+        assert torch.isnan(first.view(B, L, H)[0]).all()
+        assert torch.isnan(run_e(E3, P).view(B, L, H)[0]).all()       # cached planes, cached bound: still the dense sweep
+        E4 = E.clone()
+        assert torch.isfinite(run_e(E4, P)).all() and torch.isfinite(run_e(E4, P)).all()   # small table: skip on, twice
 
 
 def _attention_case(pkg, B, nh, L, scale, seed, lens):
